@@ -1,0 +1,304 @@
+"""CPU oracle for the NeRF volume-rendering hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a from-scratch CPU restatement (numpy + torch-CPU fp32) of the algorithm of
+kwea123/nerf_pl's `models/nerf.py` + `models/rendering.py`.  It exists so that
+the HIP kernels have something to be compared against on a machine where
+`/root/reference` does not exist (the GPU box).  It is *pinned*: `oracle/make_golden.py`
+runs the real reference (imported unmodified through `oracle/ref_shim.py`) and this
+file on identical seeded inputs and commits the reference's outputs to `tests/golden/`;
+`tests/test_oracle_golden.py` checks this file against those vectors on every run.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+this module.  The product (`nerf_pl_amd/`) never does and has no CPU fallback.
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+All RNG draws are *injected* as tensors so oracle and HIP path consume identical noise:
+the reference's draw order inside one `render_rays` call is (rendering.py:203, :152,
+:39, :152)  rand(B,S_c) [iff perturb>0] -> randn(B,S_c) -> rand(B,N_i) [iff perturb!=0]
+-> randn(B,S_f).
+"""
+import math
+
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------- parameters
+# state_dict layout of reference NeRF (models/nerf.py:60-81), default D=8 W=256 skips=[4]
+XYZ_CH = 63
+DIR_CH = 27
+W = 256
+
+
+def layer_shapes(D=8, Wd=W, in_xyz=XYZ_CH, in_dir=DIR_CH, skips=(4,)):
+    """(name, out_features, in_features) in state_dict order. nerf.py:60-81."""
+    shapes = []
+    for i in range(D):
+        if i == 0:
+            fin = in_xyz
+        elif i in skips:
+            fin = Wd + in_xyz
+        else:
+            fin = Wd
+        shapes.append((f"xyz_encoding_{i+1}.0", Wd, fin))
+    shapes.append(("xyz_encoding_final", Wd, Wd))
+    shapes.append(("dir_encoding.0", Wd // 2, Wd + in_dir))
+    shapes.append(("sigma", 1, Wd))
+    shapes.append(("rgb.0", 3, Wd // 2))
+    return shapes
+
+
+def make_params(seed, sigma_gain=1.0, sigma_bias=0.0):
+    """Deterministic, platform-independent parameters with nn.Linear's default
+    distribution U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (numpy PCG64, not torch RNG, so the
+    same weights can be rebuilt on any box from the seed alone).  `sigma_gain/bias`
+    rescale the density head to emulate a trained (peaky) field."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, fo, fi in layer_shapes():
+        b = 1.0 / math.sqrt(fi)
+        p[name + ".weight"] = torch.from_numpy(rng.uniform(-b, b, size=(fo, fi)).astype(np.float32))
+        p[name + ".bias"] = torch.from_numpy(rng.uniform(-b, b, size=(fo,)).astype(np.float32))
+    p["sigma.weight"] = p["sigma.weight"] * sigma_gain
+    p["sigma.bias"] = p["sigma.bias"] * sigma_gain + sigma_bias
+    return p
+
+
+def make_rays(seed, n, kind="blender"):
+    """Seeded synthetic rays (B,8) = [o(3) d(3) near far].  SURVEY §8d.
+    blender: o=(0,0,4)+0.1N, unit d aimed roughly at the origin, near 2 far 6 (blender.py:34-35).
+    ndc    : forward-facing NDC-style rays, near 0 far 1, NON-unit d (ray_utils.py:75-92)."""
+    g = torch.Generator().manual_seed(seed)
+    if kind == "blender":
+        o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(n, 3, generator=g)
+        tgt = 0.8 * torch.randn(n, 3, generator=g)
+        d = tgt - o
+        d = d / d.norm(dim=-1, keepdim=True)
+        near = torch.full((n, 1), 2.0)
+        far = torch.full((n, 1), 6.0)
+    elif kind == "ndc":
+        o = torch.cat([torch.rand(n, 2, generator=g) * 2 - 1, -torch.ones(n, 1)], 1)
+        d = torch.cat([0.3 * torch.randn(n, 2, generator=g), 2.0 + 0.2 * torch.rand(n, 1, generator=g)], 1)
+        near = torch.zeros(n, 1)
+        far = torch.ones(n, 1)
+    else:
+        raise ValueError(kind)
+    return torch.cat([o, d, near, far], 1).float().contiguous()
+
+
+# ----------------------------------------------------------------------------- a2: encoding
+def posenc(x, n_freqs):
+    """[x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]  nerf.py:33-38 (logscale bands :17).
+    Channel c: c<C -> x[c]; else k=(c-C)//(2C), sin if ((c-C)//C)%2==0 else cos."""
+    x = x.float()
+    n, C = x.shape
+    out = torch.empty(n, C * (2 * n_freqs + 1), dtype=torch.float32)
+    out[:, :C] = x
+    col = C
+    for k in range(n_freqs):
+        arg = x * float(2.0 ** k)  # fp32 product first, then sin/cos
+        out[:, col:col + C] = torch.sin(arg)
+        out[:, col + C:col + 2 * C] = torch.cos(arg)
+        col += 2 * C
+    return out
+
+
+# ----------------------------------------------------------------------------- a4: MLP
+def _lin(p, name, h):
+    return h @ p[name + ".weight"].t() + p[name + ".bias"]
+
+
+def mlp_forward(p, x, sigma_only=False, return_acts=False):
+    """nerf.py:100-124.  x (n,90) [or (n,63) when sigma_only] -> (n,4)=[rgb,sigma] / (n,1)."""
+    enc_xyz = x[:, :XYZ_CH]
+    h = enc_xyz
+    acts = []
+    for i in range(8):
+        if i == 4:  # skip: [input_xyz, hidden]   nerf.py:108-109
+            h = torch.cat([enc_xyz, h], -1)
+        h = torch.relu(_lin(p, f"xyz_encoding_{i+1}.0", h))
+        acts.append(h)
+    sigma = _lin(p, "sigma", h)  # raw, no activation   nerf.py:112
+    if sigma_only:
+        return (sigma, acts) if return_acts else sigma
+    feat = _lin(p, "xyz_encoding_final", h)  # no activation   nerf.py:116
+    t = torch.relu(_lin(p, "dir_encoding.0", torch.cat([feat, x[:, XYZ_CH:XYZ_CH + DIR_CH]], -1)))
+    rgb = torch.sigmoid(_lin(p, "rgb.0", t))
+    out = torch.cat([rgb, sigma], -1)  # nerf.py:122
+    return (out, acts) if return_acts else out
+
+
+# ----------------------------------------------------------------------------- a9: searchsorted
+def searchsorted_right(cdf, u):
+    """Row-wise numpy.searchsorted(side='right'): first j with cdf[r,j] > u[r,k].
+    Semantics of torchsearchsorted.searchsorted(cdf,u,side='right') (rendering.py:42).
+    Pure numpy; int64 result (B,K)."""
+    a = np.ascontiguousarray(cdf.detach().numpy() if torch.is_tensor(cdf) else cdf, dtype=np.float32)
+    v = np.ascontiguousarray(u.detach().numpy() if torch.is_tensor(u) else u, dtype=np.float32)
+    out = np.empty(v.shape, dtype=np.int64)
+    for r in range(a.shape[0]):
+        out[r] = np.searchsorted(a[r], v[r], side="right")
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------- a8: sample_pdf
+def pdf_to_cdf(weights, eps=1e-5):
+    """rendering.py:29-33.  torch-CPU cumsum on fp32 (fp64 running sum rounded per element,
+    SURVEY A.9) is kept because that IS the oracle's arithmetic."""
+    w = weights.float() + eps
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    return torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+
+
+def sample_pdf(bins, weights, n_importance, u=None, eps=1e-5, return_aux=False):
+    """Inverse-CDF sampling, rendering.py:14-55.  u=None -> deterministic linspace (:36-37),
+    else the injected (B,N_i) uniform draws (:39)."""
+    B, M = weights.shape
+    cdf = pdf_to_cdf(weights, eps)
+    if u is None:
+        u = torch.linspace(0, 1, n_importance).expand(B, n_importance)
+    u = u.contiguous().float()
+    inds = searchsorted_right(cdf, u)
+    below = torch.clamp(inds - 1, min=0)  # :43
+    above = torch.clamp(inds, max=M)  # :44
+    cdf_b = torch.gather(cdf, 1, below)
+    cdf_a = torch.gather(cdf, 1, above)
+    bin_b = torch.gather(bins, 1, below)
+    bin_a = torch.gather(bins, 1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < eps, torch.ones_like(denom), denom)  # :51
+    samples = bin_b + (u - cdf_b) / denom * (bin_a - bin_b)  # :54
+    if return_aux:
+        return samples, cdf, u, inds
+    return samples
+
+
+# ----------------------------------------------------------------------------- a5: z sampling
+def coarse_z(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
+    """rendering.py:183-204."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    t = torch.linspace(0, 1, n_samples)
+    if not use_disp:
+        z = near * (1 - t) + far * t
+    else:
+        z = 1 / (1 / near * (1 - t) + 1 / far * t)
+    z = z.expand(rays.shape[0], n_samples)
+    if perturb > 0:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper = torch.cat([mid, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * (perturb * perturb_rand)
+    return z.contiguous()
+
+
+# ----------------------------------------------------------------------------- a7: compositing
+def composite(sigmas, rgbs, z, rays_d, noise, white_back=False):
+    """rendering.py:143-172.  sigmas (B,S) raw; rgbs (B,S,3) or None (weights only);
+    noise (B,S) ALREADY multiplied by noise_std (or None == 0).
+    Returns dict(weights, opacity[, rgb, depth])."""
+    deltas = z[:, 1:] - z[:, :-1]
+    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1)  # :145-146
+    deltas = deltas * torch.norm(rays_d.unsqueeze(1), dim=-1)  # :150
+    s = sigmas if noise is None else sigmas + noise
+    alphas = 1 - torch.exp(-deltas * torch.relu(s))  # :155
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)  # :156-157
+    weights = alphas * torch.cumprod(shifted, -1)[:, :-1]  # :158-159
+    out = {"weights": weights, "opacity": weights.sum(1)}
+    if rgbs is not None:
+        rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)  # :166
+        out["depth"] = torch.sum(weights * z, -1)  # :167
+        if white_back:
+            rgb = rgb + 1 - out["opacity"].unsqueeze(-1)  # :169-170
+        out["rgb"] = rgb
+    return out
+
+
+# ----------------------------------------------------------------------------- a6/a10: render
+def _infer(p, rays, z, dir_enc, noise, white_back, weights_only, n_freq_xyz=10):
+    """`inference` closure, rendering.py:91-172 (point-chunk loop :125-133 collapsed: it is
+    only a memory bound, results are chunk-invariant)."""
+    B, S = z.shape
+    xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]  # :206-207 / :231-232
+    enc = posenc(xyz.reshape(-1, 3), n_freq_xyz)
+    if weights_only:
+        sig = mlp_forward(p, enc, sigma_only=True).view(B, S)
+        return composite(sig, None, z, rays[:, 3:6], noise, white_back)
+    x = torch.cat([enc, dir_enc.repeat_interleave(S, 0)], 1)  # :119,:129
+    o = mlp_forward(p, x).view(B, S, 4)
+    res = composite(o[..., 3], o[..., :3], z, rays[:, 3:6], noise, white_back)
+    res["raw"] = o
+    return res
+
+
+def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1,
+                N_importance=0, white_back=False, test_time=False, rng=None, return_aux=False):
+    """rendering.py:58-244 with injected RNG.  params = [coarse_dict, fine_dict].
+    rng keys: 'perturb_rand' (B,S_c) U[0,1), 'noise_coarse' (B,S_c) N(0,1),
+              'u' (B,N_i) U[0,1), 'noise_fine' (B,S_f) N(0,1)."""
+    rng = rng or {}
+    rays = rays.float()
+    dir_enc = posenc(rays[:, 3:6], 4)  # :186 (raw, possibly non-unit d)
+    z = coarse_z(rays, N_samples, use_disp, perturb, rng.get("perturb_rand"))
+
+    def nz(key):
+        if noise_std == 0 or key not in rng:
+            return None
+        return rng[key] * noise_std  # :152
+
+    aux = {"z_coarse": z}
+    c = _infer(params[0], rays, z, dir_enc, nz("noise_coarse"), white_back, weights_only=test_time)
+    if test_time:  # :209-213
+        result = {"opacity_coarse": c["opacity"]}
+    else:
+        result = {"rgb_coarse": c["rgb"], "depth_coarse": c["depth"], "opacity_coarse": c["opacity"]}
+    aux["weights_coarse"] = c["weights"]
+    if N_importance > 0:  # :222-242
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        u = rng.get("u") if perturb != 0 else None  # det=(perturb==0)  :226
+        z_new = sample_pdf(mid, c["weights"][:, 1:-1], N_importance, u=u).detach()  # :226
+        zf, _ = torch.sort(torch.cat([z, z_new], -1), -1)  # :229
+        f = _infer(params[1], rays, zf, dir_enc, nz("noise_fine"), white_back, weights_only=False)
+        result["rgb_fine"] = f["rgb"]
+        result["depth_fine"] = f["depth"]
+        result["opacity_fine"] = f["opacity"]
+        aux.update(z_new=z_new, z_fine=zf, weights_fine=f["weights"])
+    return (result, aux) if return_aux else result
+
+
+def draw_rng(seed, B, S_c, N_i, perturb):
+    """Seeded RNG tensors in the reference's consumption order."""
+    g = torch.Generator().manual_seed(seed)
+    r = {}
+    if perturb > 0:
+        r["perturb_rand"] = torch.rand(B, S_c, generator=g)
+    r["noise_coarse"] = torch.randn(B, S_c, generator=g)
+    if N_i > 0:
+        if perturb != 0:
+            r["u"] = torch.rand(B, N_i, generator=g)
+        r["noise_fine"] = torch.randn(B, S_c + N_i, generator=g)
+    return r
+
+
+# ----------------------------------------------------------------------------- a12: loss
+def mse_loss(result, target):
+    """losses.py:9-14."""
+    loss = torch.mean((result["rgb_coarse"] - target) ** 2)
+    if "rgb_fine" in result:
+        loss = loss + torch.mean((result["rgb_fine"] - target) ** 2)
+    return loss
+
+
+def psnr(pred, gt):
+    """metrics.py:4-13."""
+    return -10 * torch.log10(torch.mean((pred - gt) ** 2))
+
+
+def grad_digest(g):
+    """Compact fingerprint of a gradient tensor for golden files: [sum, l2, first 8, last 8]."""
+    f = g.reshape(-1).double()
+    head = f[:8]
+    tail = f[-8:]
+    if head.numel() < 8:
+        head = torch.cat([head, torch.zeros(8 - head.numel(), dtype=torch.float64)])
+        tail = torch.cat([tail, torch.zeros(8 - tail.numel(), dtype=torch.float64)])
+    return torch.cat([f.sum()[None], f.norm()[None], head, tail]).float()

@@ -1,0 +1,87 @@
+"""CPU: the oracle restatement (oracle/nerf_oracle.py) against the golden vectors minted from
+the real reference by oracle/make_golden.py.  This is what pins the oracle."""
+import torch
+
+from oracle import nerf_oracle as O
+
+
+def test_embedding_bit_exact(golden):
+    x = golden["emb_x"]
+    assert torch.equal(O.posenc(x, 10), golden["emb_out63"])
+    assert torch.equal(O.posenc(x, 4), golden["emb_out27"])
+
+
+def test_mlp_forward(golden):
+    p = O.make_params(int(golden["mlp_seed"]))
+    out = O.mlp_forward(p, golden["mlp_x"])
+    sig = O.mlp_forward(p, golden["mlp_x"][:, :63], sigma_only=True)
+    # same fp32 GEMM library, only bias-add fusion differs -> a few ulp
+    assert torch.allclose(out, golden["mlp_out"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sig, golden["mlp_sigma"], rtol=1e-5, atol=1e-6)
+
+
+def test_searchsorted_indices_bit_exact(golden):
+    for tag in ("det64", "det128"):
+        inds = O.searchsorted_right(golden[f"ss_{tag}_cdf"], golden[f"ss_{tag}_u"])
+        assert inds.dtype == torch.int64
+        assert torch.equal(inds, golden[f"ss_{tag}_inds"])
+    inds = O.searchsorted_right(golden["ss_rand_cdf"], golden["sp_rand_u"])
+    assert torch.equal(inds, golden["ss_rand_inds"])
+
+
+def test_cdf_bit_exact(golden):
+    assert torch.equal(O.pdf_to_cdf(golden["sp_w"]), golden["ss_det64_cdf"])
+    assert torch.equal(O.pdf_to_cdf(golden["sp_w"]), golden["ss_rand_cdf"])
+
+
+def test_sample_pdf(golden):
+    bins, w = golden["sp_bins"], golden["sp_w"]
+    for n in (64, 128):
+        assert torch.equal(O.sample_pdf(bins, w, n), golden[f"sp_det{n}"])
+    assert torch.equal(O.sample_pdf(bins, w, 128, u=golden["sp_rand_u"]), golden["sp_rand128"])
+
+
+def _case(golden, name):
+    cfg = golden[f"rr_{name}_cfg"].tolist()
+    kind = {0: "blender", 1: "ndc"}[int(cfg[0])]
+    B, S_c, N_i = int(cfg[1]), int(cfg[2]), int(cfg[3])
+    disp, pert, nstd, wb, tt, sg, sb, seed = bool(cfg[4]), cfg[5], cfg[6], bool(cfg[7]), bool(cfg[8]), cfg[9], cfg[10], int(cfg[11])
+    params = [O.make_params(seed, sg, sb), O.make_params(seed + 500, sg, sb)]
+    rays = O.make_rays(seed, B, kind)
+    rng = O.draw_rng(seed, B, S_c, N_i, pert)
+    return params, rays, dict(N_samples=S_c, use_disp=disp, perturb=pert, noise_std=nstd, N_importance=N_i,
+                              white_back=wb, test_time=tt, rng=rng)
+
+
+def test_render_rays_all_cases(golden):
+    for name in golden["rr_names"].tolist():
+        params, rays, kw = _case(golden, name)
+        res = O.render_rays(params, rays, **kw)
+        keys = [k[len(f"rr_{name}_"):] for k in golden if k.startswith(f"rr_{name}_") and not k.endswith("_cfg")]
+        assert sorted(keys) == sorted(res.keys()), (name, keys, list(res))
+        for k in keys:
+            ref = golden[f"rr_{name}_{k}"]
+            assert torch.allclose(res[k], ref, rtol=1e-4, atol=2e-5), (name, k, (res[k] - ref).abs().max())
+
+
+def test_training_gradients(golden):
+    cfg = golden["gr_cfg"].tolist()
+    B, S_c, N_i, pert, nstd, wb, sg, sb, seed = int(cfg[1]), int(cfg[2]), int(cfg[3]), cfg[5], cfg[6], bool(cfg[7]), cfg[9], cfg[10], int(cfg[11])
+    pc, pf = O.make_params(seed, sg, sb), O.make_params(seed + 500, sg, sb)
+    for d in (pc, pf):
+        for v in d.values():
+            v.requires_grad_(True)
+    rays = O.make_rays(seed, B, "blender")
+    rng = O.draw_rng(seed, B, S_c, N_i, pert)
+    res = O.render_rays([pc, pf], rays, S_c, False, pert, nstd, N_i, wb, False, rng=rng)
+    loss = O.mse_loss(res, golden["gr_target"])
+    loss.backward()
+    assert torch.allclose(loss.detach(), golden["gr_loss"], rtol=1e-5)
+    for tag, d in (("c", pc), ("f", pf)):
+        for n, v in d.items():
+            dig = O.grad_digest(v.grad)
+            ref = golden[f"gr_{tag}_{n}"]
+            scale = ref[1].abs().item() + 1e-12  # l2 norm of the tensor
+            assert (dig - ref).abs().max().item() <= 2e-4 * scale + 1e-9, (tag, n, dig, ref)
+    assert torch.allclose(pc["sigma.weight"].grad, golden["gr_full_c_sigma.weight"], rtol=1e-3, atol=1e-7)
+    assert torch.allclose(pf["rgb.0.weight"].grad, golden["gr_full_f_rgb.0.weight"], rtol=1e-3, atol=1e-7)
