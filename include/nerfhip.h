@@ -1,0 +1,121 @@
+/* nerfhip.h — C ABI of libnerfhip.so: the MI355X (gfx950) NeRF volume-rendering hot path.
+ *
+ * Drop-in boundary for kwea123/nerf_pl's `models/nerf.py` + `models/rendering.py`.
+ * The reference has no FFI of its own for this path except the `torchsearchsorted`
+ * extension (rendering.py:2,42); every other entry point below replaces a *sequence of
+ * ATen launches* inside one reference Python function, cited per function
+ * (paths relative to the reference root, line numbers as in SURVEY.md).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All pointers are DEVICE pointers
+ *     (HBM) unless the name ends in `_host`.  All tensors are dense row-major fp32 unless noted.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates
+ *     nothing and keeps no mutable global state => every entry point is hipGraph-capturable.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Nothing synchronises.
+ *   - return value: 0 on success, a positive hipError_t, or a negative NERFHIP_E* code.
+ *     Nothing throws across the ABI.
+ */
+#ifndef NERFHIP_H
+#define NERFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFHIP_ABI_VERSION 1
+
+#define NERFHIP_E_BADARG (-1)  /* null pointer / non-positive size / unsupported shape */
+#define NERFHIP_E_UNSUPPORTED (-2)
+#define NERFHIP_E_ALIGN (-3)   /* pointer not aligned as documented */
+
+/* MLP arithmetic type (`dtype` arguments). */
+#define NERFHIP_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32 (parity configuration)      */
+#define NERFHIP_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (roofline config)    */
+
+typedef void* nerfhip_stream_t;
+
+int nerfhip_abi_version(void);
+const char* nerfhip_error_string(int code);
+
+/* ---- a2. Embedding.forward  (models/nerf.py:21-38) -------------------------------------
+ * out[i, :] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(F-1) x), cos(2^(F-1) x)]
+ * x (n,C) -> out (n, C*(2F+1)).  1 <= C <= 8, 0 <= F <= 16.                               */
+int nerfhip_posenc(const float* x, float* out, int64_t n, int C, int n_freqs, nerfhip_stream_t stream);
+/* backward of the above w.r.t. x: gx (n,C) = d<gout,out>/dx.                              */
+int nerfhip_posenc_bwd(const float* x, const float* gout, float* gx, int64_t n, int C, int n_freqs,
+                       nerfhip_stream_t stream);
+
+/* ---- a5. coarse depth sampling  (models/rendering.py:183-204) --------------------------
+ * rays (B,8)=[o d near far]; z (B,S): linear in depth or disparity; when perturb>0,
+ * stratified jitter with `perturb_rand` (B,S) ~ U[0,1) (the caller's torch.rand draw).     */
+int nerfhip_sample_coarse_z(const float* rays, const float* perturb_rand, float* z, int64_t B, int S,
+                            int use_disp, float perturb, nerfhip_stream_t stream);
+
+/* ---- a9. torchsearchsorted.searchsorted(a, v, side='right')  (rendering.py:2,42) --------
+ * idx[r,k] = first j in [0,M] with a[r,j] > v[r,k]  (numpy side='right'); a (B,M), v (B,K),
+ * idx int64 (B,K).  This is the one native extension the reference depends on.             */
+int nerfhip_searchsorted_right(const float* a, const float* v, int64_t* idx, int64_t B, int M, int K,
+                               nerfhip_stream_t stream);
+/* side='left' (the extension's default; unused by the reference): first j with a[r,j] >= v[r,k]. */
+int nerfhip_searchsorted_left(const float* a, const float* v, int64_t* idx, int64_t B, int M, int K,
+                              nerfhip_stream_t stream);
+
+/* ---- a8. sample_pdf  (models/rendering.py:14-55) ----------------------------------------
+ * bins (B,M+1) with row stride `bins_stride`, weights (B,M) with row stride `w_stride`
+ * (so that the reference's `weights_coarse[:, 1:-1]` view needs no copy).
+ * u: NULL => deterministic linspace(0,1,K) (`det=True`); else (K) if u_stride==0 or (B,K).
+ * samples (B,K).                                                                           */
+int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
+                       const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K, float eps,
+                       nerfhip_stream_t stream);
+
+/* ---- a10. fine-pass depth assembly  (models/rendering.py:223-229) -----------------------
+ * z_mid = midpoints(z_coarse); z_new = sample_pdf(z_mid, w_coarse[:,1:-1], N_i, u);
+ * z_fine = sort(cat(z_coarse, z_new)).  One launch, one wave per ray.
+ * z_coarse,w_coarse (B,S_c); u as above; z_fine (B,S_c+N_i); z_new (B,N_i) optional (NULL ok). */
+int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
+                   float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
+                   nerfhip_stream_t stream);
+
+/* ---- a7. alpha compositing  (models/rendering.py:143-172) -------------------------------
+ * raw: (B,S,4)=[r g b sigma] when raw_ch==4, or (B,S) sigma only when raw_ch==1 (weights_only).
+ * noise: (B,S) standard-normal draws or NULL; sigma_eff = relu(sigma + noise*noise_std).
+ * weights (B,S) always written; opacity (B) always; rgb (B,3) and depth (B) when raw_ch==4.  */
+int nerfhip_composite_fwd(const float* raw, int raw_ch, const float* z, const float* rays,
+                          const float* noise, float noise_std, int white_back, float* weights, float* rgb,
+                          float* depth, float* opacity, int64_t B, int S, nerfhip_stream_t stream);
+/* backward: given g_rgb (B,3) [, g_depth (B), g_opacity (B); NULL = 0] produce g_raw (B,S,raw_ch).
+ * Recomputes alpha/T from raw,z,noise (nothing else is saved by forward).                   */
+int nerfhip_composite_bwd(const float* raw, int raw_ch, const float* z, const float* rays,
+                          const float* noise, float noise_std, int white_back, const float* g_rgb,
+                          const float* g_depth, const float* g_opacity, const float* g_weights,
+                          float* g_raw, int64_t B, int S, nerfhip_stream_t stream);
+
+/* ---- a3/a4. NeRF MLP  (models/nerf.py:42-124; D=8 W=256 skips=[4] in 63/27) -------------
+ * Parameters are repacked once per weight update into the MFMA A-fragment stream the
+ * kernel consumes (layout: DESIGN.md §3).  weights_host[i]/biases_host[i] are HOST arrays of
+ * 12 DEVICE pointers in state_dict order: xyz_encoding_1..8, xyz_encoding_final,
+ * dir_encoding, sigma, rgb (each weight (out,in) row-major fp32).                           */
+size_t nerfhip_mlp_packed_bytes(int dtype);
+int nerfhip_mlp_pack_weights(const float* const* weights_host, const float* const* biases_host, void* packed,
+                             int dtype, nerfhip_stream_t stream);
+
+/* NeRF.forward(x, sigma_only) on pre-embedded inputs (nerf.py:83-124):
+ * x (n, 90 | 63) with row stride x_stride floats -> out (n,4)=[rgb sigma] | (n,1).          */
+int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const void* packed, float* out,
+                             int sigma_only, int dtype, nerfhip_stream_t stream);
+
+/* Fused `inference` MLP loop (rendering.py:115-141 + 206-207 + nerf.py:21-38): points are
+ * generated in-register as o + d*z, encoded (10 / 4 frequencies) and pushed through the MLP;
+ * no (n,63)/(n,90) tensor and no repeat_interleave'd dir embedding ever exists in HBM.
+ * rays (B,8), z (B,S) -> out (B,S,4) | (B,S) when sigma_only.                               */
+int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, const void* packed, float* out,
+                         int sigma_only, int dtype, nerfhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFHIP_H */

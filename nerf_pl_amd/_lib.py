@@ -1,0 +1,98 @@
+"""ctypes binding of libnerfhip.so (C ABI: include/nerfhip.h).
+
+The product has NO CPU or eager-PyTorch fallback: if the HIP library is missing or a call is made
+on a non-GPU tensor, this raises.  torch is imported first so that the library's
+libamdhip64.so.7 dependency binds to the HIP runtime torch already loaded (one runtime per process).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnerfhip.so")
+
+F32, BF16 = 0, 1
+
+_c_void_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/nerfhip.h exactly
+SIGNATURES = {
+    "nerfhip_abi_version": [],
+    "nerfhip_error_string": [_int],
+    "nerfhip_posenc": [_c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_posenc_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_sample_coarse_z": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _f32, _c_void_p],
+    "nerfhip_searchsorted_right": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_searchsorted_left": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_sample_pdf": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _int, _int, _f32,
+                           _c_void_p],
+    "nerfhip_fine_z": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _int, _int, _f32,
+                       _c_void_p],
+    "nerfhip_composite_fwd": [_c_void_p, _int, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _c_void_p,
+                              _c_void_p, _c_void_p, _i64, _int, _c_void_p],
+    "nerfhip_composite_bwd": [_c_void_p, _int, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _c_void_p,
+                              _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
+    "nerfhip_mlp_packed_bytes": [_int],
+    "nerfhip_mlp_pack_weights": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
+    "nerfhip_mlp_fwd_embedded": [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _int, _int, _c_void_p],
+    "nerfhip_mlp_fwd_rays": [_c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _int, _int, _c_void_p],
+}
+_RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t}
+
+_lib = None
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libnerfhip.so and bind every symbol of the header.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NerfHipError(
+            "libnerfhip.so not built: run `python -m nerf_pl_amd.build` (needs hipcc, gfx950). "
+            "There is no CPU/eager fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    if lib.nerfhip_abi_version() != 1:
+        raise NerfHipError("libnerfhip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nerfhip_error_string(code)
+        raise NerfHipError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (kernels launch there: DDP overlap, graph capture)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NerfHipError("nerf_pl_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+        if t.dtype != torch.float32:
+            raise NerfHipError("expected float32 tensor, got %s" % t.dtype)

@@ -1,0 +1,248 @@
+// K4 / K4b: alpha compositing of one ray per 64-lane wavefront — replaces the ~15-launch
+// sub/cat/mul/norm/relu/exp/cat/cumprod/mul/sum sequence of `inference` (reference
+// models/rendering.py:143-172) and its autograd mirror.  HBM-bound: S*(16+4[+4]) B in and
+// S*4 + 20 B out per ray, every byte touched once, loads coalesced along the sample axis.
+// Transmittance is a wave-wide exclusive prefix product (fp64, rounded per element like
+// torch-CPU cumprod) chained across 64-sample chunks.
+#include "common.h"
+
+// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
+// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
+#pragma clang fp contract(off)
+
+namespace nerfhip {
+
+struct RayGeom {
+    float dnorm;
+};
+
+__device__ __forceinline__ float ray_dnorm(const float* __restrict__ rays, int64_t r) {
+    const float dx = rays[r * 8 + 3], dy = rays[r * 8 + 4], dz = rays[r * 8 + 5];
+    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));  // :150
+}
+
+// per-sample quantities shared by forward and backward
+struct SampleTerms {
+    float delta;  // (z[i+1]-z[i] | 1e10) * |d|
+    float e;      // exp(-delta * relu(sigma+noise)) = 1 - alpha
+    float alpha;
+    float sh;     // (1 - alpha) + 1e-10, the factor entering the transmittance product
+    bool on;      // relu gate open
+};
+
+__device__ __forceinline__ SampleTerms sample_terms(float z_i, float z_next, bool last, float dnorm, float sigma,
+                                                    float noise) {
+    SampleTerms t;
+    const float d = last ? 1e10f : __fsub_rn(z_next, z_i);   // :144-146
+    t.delta = __fmul_rn(d, dnorm);                            // :150
+    const float s = __fadd_rn(sigma, noise);
+    t.on = s > 0.0f;
+    const float sr = t.on ? s : 0.0f;                         // relu   :155
+    t.e = expf(-__fmul_rn(t.delta, sr));
+    t.alpha = __fsub_rn(1.0f, t.e);
+    t.sh = __fadd_rn(__fsub_rn(1.0f, t.alpha), 1e-10f);       // :157
+    return t;
+}
+
+template <int RAW_CH>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ raw,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ rays,
+                                                             const float* __restrict__ noise, float noise_std,
+                                                             int white_back, float* __restrict__ weights,
+                                                             float* __restrict__ rgb, float* __restrict__ depth,
+                                                             float* __restrict__ opacity, int64_t B, int S) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    const float dnorm = ray_dnorm(rays, r);
+    const float* zr = z + r * S;
+    double carry = 1.0;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_o = 0.f;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < S;
+        float sigma = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, zi = 0.f, zn = 0.f, nz = 0.f;
+        if (valid) {
+            zi = zr[i];
+            zn = (i + 1 < S) ? zr[i + 1] : zi;
+            if (RAW_CH == 4) {
+                const float4 v = reinterpret_cast<const float4*>(raw)[r * S + i];
+                cr = v.x; cg = v.y; cb = v.z; sigma = v.w;
+            } else {
+                sigma = raw[r * S + i];
+            }
+            if (noise) nz = __fmul_rn(noise[r * S + i], noise_std);   // :152
+        }
+        const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
+        const double f = valid ? (double)t.sh : 1.0;
+        const double incl = wave_incl_prod(f, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(excl * carry);                        // cumprod(...)[:, :-1]  :158-159
+        carry = carry * __shfl(incl, 63, 64);
+        const float w = valid ? __fmul_rn(t.alpha, T) : 0.0f;
+        if (valid) weights[r * S + i] = w;
+        acc_o += w;
+        if (RAW_CH == 4) {
+            acc_r += w * cr; acc_g += w * cg; acc_b += w * cb;
+            acc_d += w * zi;
+        }
+    }
+    acc_o = wave_sum(acc_o);
+    if (RAW_CH == 4) {
+        acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b); acc_d = wave_sum(acc_d);
+    }
+    if (lane == 0) {
+        opacity[r] = acc_o;                                           // weights.sum(1)  :160
+        if (RAW_CH == 4) {
+            const float bg = white_back ? __fsub_rn(1.0f, acc_o) : 0.0f;   // :169-170
+            rgb[r * 3 + 0] = acc_r + bg;
+            rgb[r * 3 + 1] = acc_g + bg;
+            rgb[r * 3 + 2] = acc_b + bg;
+            depth[r] = acc_d;                                          // :167
+        }
+    }
+}
+
+// Backward.  L depends on raw through  rgb = sum_i w_i c_i + wb*(1-sum w),  depth = sum w z,
+// opacity = sum w, and (optionally) the weights themselves.  With gw_i = dL/dw_i:
+//   dL/dc_i     = w_i * g_rgb
+//   dL/dalpha_i = gw_i*T_i - (sum_{k>i} gw_k w_k) / sh_i         (T_k carries the factor sh_i for k>i)
+//   dL/dsigma_i = dL/dalpha_i * delta_i * e_i * [sigma_i+noise_i > 0]
+template <int RAW_CH>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ rays,
+                                                             const float* __restrict__ noise, float noise_std,
+                                                             int white_back, const float* __restrict__ g_rgb,
+                                                             const float* __restrict__ g_depth,
+                                                             const float* __restrict__ g_opacity,
+                                                             const float* __restrict__ g_weights,
+                                                             float* __restrict__ g_raw, int64_t B, int S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    float* T_s = lds + (size_t)wave * 2 * S;   // transmittance T_i
+    float* gw_s = T_s + S;                     // dL/dw_i
+    const float dnorm = ray_dnorm(rays, r);
+    const float* zr = z + r * S;
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (RAW_CH == 4 && g_rgb) { gr = g_rgb[r * 3]; gg = g_rgb[r * 3 + 1]; gb = g_rgb[r * 3 + 2]; }
+    const float gd = (RAW_CH == 4 && g_depth) ? g_depth[r] : 0.f;
+    float gconst = g_opacity ? g_opacity[r] : 0.f;
+    if (RAW_CH == 4 && white_back) gconst -= (gr + gg + gb);
+    // forward sweep: transmittance + dL/dw + colour gradients
+    double carry = 1.0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < S;
+        float sigma = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, zi = 0.f, zn = 0.f, nz = 0.f;
+        if (valid) {
+            zi = zr[i];
+            zn = (i + 1 < S) ? zr[i + 1] : zi;
+            if (RAW_CH == 4) {
+                const float4 v = reinterpret_cast<const float4*>(raw)[r * S + i];
+                cr = v.x; cg = v.y; cb = v.z; sigma = v.w;
+            } else {
+                sigma = raw[r * S + i];
+            }
+            if (noise) nz = __fmul_rn(noise[r * S + i], noise_std);
+        }
+        const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
+        const double f = valid ? (double)t.sh : 1.0;
+        const double incl = wave_incl_prod(f, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(excl * carry);
+        carry = carry * __shfl(incl, 63, 64);
+        if (valid) {
+            const float w = t.alpha * T;
+            float gw = gconst + (g_weights ? g_weights[r * S + i] : 0.f);
+            if (RAW_CH == 4) {
+                gw += gr * cr + gg * cg + gb * cb + gd * zi;
+                float* o = g_raw + (r * S + i) * 4;
+                o[0] = w * gr; o[1] = w * gg; o[2] = w * gb;
+            }
+            T_s[i] = T;
+            gw_s[i] = gw;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // reverse sweep: exclusive suffix sum of gw_k*w_k, then dL/dsigma
+    float tail = 0.f;
+    const int nchunk = (S + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int i = c * 64 + lane;
+        const bool valid = i < S;
+        SampleTerms t{};
+        float T = 0.f, gw = 0.f;
+        if (valid) {
+            const float zi = zr[i];
+            const float zn = (i + 1 < S) ? zr[i + 1] : zi;
+            const float sigma = (RAW_CH == 4) ? raw[(r * S + i) * 4 + 3] : raw[r * S + i];
+            const float nz = noise ? __fmul_rn(noise[r * S + i], noise_std) : 0.f;
+            t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
+            T = T_s[i];
+            gw = gw_s[i];
+        }
+        const float v = valid ? gw * (t.alpha * T) : 0.f;
+        float incl = v;   // inclusive suffix scan: lane l gets the sum over lanes >= l
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float tt = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += tt;
+        }
+        const float suf = (incl - v) + tail;   // strictly-after sum
+        tail += __shfl(incl, 0, 64);
+        if (valid) {
+            const float g_alpha = gw * T - suf / t.sh;
+            const float g_sigma = t.on ? g_alpha * t.delta * t.e : 0.f;
+            g_raw[(r * S + i) * RAW_CH + (RAW_CH - 1)] = g_sigma;
+        }
+    }
+}
+
+}  // namespace nerfhip
+
+extern "C" int nerfhip_composite_fwd(const float* raw, int raw_ch, const float* z, const float* rays,
+                                     const float* noise, float noise_std, int white_back, float* weights, float* rgb,
+                                     float* depth, float* opacity, int64_t B, int S, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 1 && (raw_ch == 1 || raw_ch == 4));
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(raw && z && rays && weights && opacity);
+    if (raw_ch == 4) {
+        NERFHIP_CHECK_ARG(rgb && depth);
+        if (((uintptr_t)raw) & 15) return NERFHIP_E_ALIGN;
+    }
+    if (noise_std == 0.0f) noise = nullptr;
+    dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    if (raw_ch == 4)
+        hipLaunchKernelGGL(nerfhip::composite_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, raw, z, rays, noise,
+                           noise_std, white_back, weights, rgb, depth, opacity, B, S);
+    else
+        hipLaunchKernelGGL(nerfhip::composite_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, raw, z, rays, noise,
+                           noise_std, white_back, weights, rgb, depth, opacity, B, S);
+    return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_composite_bwd(const float* raw, int raw_ch, const float* z, const float* rays,
+                                     const float* noise, float noise_std, int white_back, const float* g_rgb,
+                                     const float* g_depth, const float* g_opacity, const float* g_weights,
+                                     float* g_raw, int64_t B, int S, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 1 && S <= 2048 && (raw_ch == 1 || raw_ch == 4));
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(raw && z && rays && g_raw);
+    if (raw_ch == 4 && (((uintptr_t)raw) & 15)) return NERFHIP_E_ALIGN;
+    if (noise_std == 0.0f) noise = nullptr;
+    dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    size_t lds = (size_t)4 * 2 * S * sizeof(float);
+    if (raw_ch == 4)
+        hipLaunchKernelGGL(nerfhip::composite_bwd_kernel<4>, grid, block, lds, (hipStream_t)stream, raw, z, rays,
+                           noise, noise_std, white_back, g_rgb, g_depth, g_opacity, g_weights, g_raw, B, S);
+    else
+        hipLaunchKernelGGL(nerfhip::composite_bwd_kernel<1>, grid, block, lds, (hipStream_t)stream, raw, z, rays,
+                           noise, noise_std, white_back, g_rgb, g_depth, g_opacity, g_weights, g_raw, B, S);
+    return nerfhip_launch_status();
+}

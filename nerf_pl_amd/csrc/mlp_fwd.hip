@@ -1,0 +1,355 @@
+// K2: fused NeRF MLP forward — replaces, per `inference` call, the point-chunk loop of
+// reference models/rendering.py:115-141 (embedding_xyz -> cat -> model) together with
+// Embedding.forward (models/nerf.py:21-38) and NeRF.forward (models/nerf.py:83-124):
+// ~70 ATen launches and ~5 KB/point of HBM round trips per chunk become one launch whose only HBM
+// traffic is 4 B in (z) + 16 B out (rgb,sigma) per point plus the L2-resident weight stream.
+//
+// Mapping (MFMA-bound): one wavefront owns 32 points for the whole network; activations
+// never leave its registers (C/D fragment of layer l == B operand of layer l+1, see mlp_layout.h);
+// the weights — pre-packed in A-fragment order — are DMA'd global->LDS (global_load_lds_dwordx4,
+// lane-linear 1 KiB pieces) into a 3-slot x 32 KiB ring shared by the workgroup's waves, with one
+// s_barrier per 32 KiB chunk and two chunks always in flight (counted vmcnt, never drained to 0).
+//   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, 8 waves (2 per SIMD) = 256 points / workgroup
+//   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), 4 waves (1 per SIMD) = 128 points / workgroup
+#include "common.h"
+
+// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
+// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
+#pragma clang fp contract(off)
+#include "mlp_layout.h"
+
+namespace nerfhip {
+using namespace mlp;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int PREC> struct PrecTraits;
+template <> struct PrecTraits<NERFHIP_BF16> {
+    using Slab = bf16x8;                 // 8 input features of one point (4 VGPRs)
+    static constexpr int NW = 8;         // waves per workgroup
+    static constexpr int WPS = 2;        // waves per SIMD (launch bound)
+};
+template <> struct PrecTraits<NERFHIP_F32> {
+    using Slab = f32x8;                  // 8 VGPRs
+    static constexpr int NW = 4;
+    static constexpr int WPS = 1;
+};
+
+__device__ __forceinline__ void make_slab(bf16x8& s, const float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = (__bf16)v[j];
+}
+__device__ __forceinline__ void make_slab(f32x8& s, const float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = v[j];
+}
+
+// one 16-byte-per-lane global->LDS DMA; LDS destination = wave-uniform `lds_dst` + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int PREC, int NCH>
+struct WeightStream {
+    static constexpr int NW = PrecTraits<PREC>::NW;
+    static constexpr int LPW = kChunkPieces / NW;   // DMA instructions per wave per chunk
+    const uint8_t* gsrc;     // packed + lane*16
+    unsigned lds_base;       // LDS byte address of the ring
+    int wave;                // wave index in the workgroup (SGPR)
+
+    __device__ __forceinline__ void issue_chunk(int c) const {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int piece = wave + i * NW;
+            glds16(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
+                   lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
+        }
+    }
+    // Called by every wave right before the first piece of chunk c is read.
+    __device__ __forceinline__ void boundary(int c) const {
+        // (1) my DMAs for chunk c have landed (chunk c+1's may stay in flight), my LDS reads of chunk c-1
+        // have returned; (2) barrier: same holds for every wave => chunk c is readable and the slot of
+        // chunk c-1 is free; (3) refill that slot with chunk c+2.
+        if (c + 1 < NCH) {
+            if (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (c + 2 < NCH) issue_chunk(c + 2);
+    }
+};
+
+__device__ __forceinline__ f32x16 mma_frag(f32x16 acc, const bf16x8& a, const bf16x8& b) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// ---- one layer: acc[t] = bias + sum over slabs W_frag(ks,t) * B[ks] -----------------------------
+template <int PREC, int L, int NCH, int NT, typename Slab>
+__device__ __forceinline__ void run_layer(const WeightStream<PREC, NCH>& st, const char* smem_lane,
+                                          const char* smem_half, const Slab* enc, const Slab* chain,
+                                          f32x16 (&acc)[NT]) {
+    constexpr Layer ly = kLayers[L];
+    static_assert(ly.nt == NT, "tile count mismatch");
+    constexpr int G0 = layer_start(L, PREC);
+    constexpr int PPF = ppf(PREC);
+    constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
+
+    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
+
+    // bias piece -> accumulator init.  Row of reg r: 32t + (r&3) + 8(r>>2) + 4h  => one f32x4 per (t, r>>2).
+    if (G0 % kChunkPieces == 0) st.boundary(G0 / kChunkPieces);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(smem_half + piece_off(G0) + (32 * t + 8 * q) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][4 * q + i] = b[i];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const Slab bs = (ks < ly.enc_slabs) ? enc[ks < ly.enc_slabs ? ks : 0]
+                                            : chain[ks >= ly.enc_slabs ? ks - ly.enc_slabs : 0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int g = G0 + 1 + (ks * NT + t) * PPF;
+            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
+            if constexpr (PREC == NERFHIP_BF16) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs, acc[t], 0, 0, 0);
+            } else {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
+                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bs[j], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <bool RELU, int NT, typename Slab>
+__device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = acc[t][8 * s + j];
+                v[j] = RELU ? fmaxf(x, 0.0f) : x;
+            }
+            make_slab(out[2 * t + s], v);
+        }
+    }
+}
+
+// ---- input encodings in slot order (mlp_layout.h: enc_slot_channel) -----------------------------
+// computed from the raw 3-vector: half h evaluates frequencies k = 2i+h; one sincos -> two slots
+template <int F, int SLABS, typename Slab>
+__device__ __forceinline__ void encode_slots(const float (&v)[3], int h, Slab* out) {
+    constexpr int NPAIR = 3 * (F / 2);
+    float slots[8 * SLABS];
+    float vs[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vs[c] = h ? 2.0f * v[c] : v[c];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const int i = p / 3, c = p % 3;
+        const float arg = vs[c] * (float)(1 << (2 * i));   // x * 2^(2i+h): exact power-of-two scaling
+        float s, co;
+        sincosf(arg, &s, &co);
+        slots[2 * p] = s;
+        slots[2 * p + 1] = co;
+    }
+#pragma unroll
+    for (int idx = 2 * NPAIR; idx < 8 * SLABS; ++idx) {
+        const int tail = idx - 2 * NPAIR;
+        slots[idx] = (tail == 0) ? (h ? v[2] : v[0]) : (tail == 1) ? (h ? 0.0f : v[1]) : 0.0f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < SLABS; ++ks) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = slots[8 * ks + j];
+        make_slab(out[ks], t8);
+    }
+}
+// gathered from a pre-embedded row (NeRF.forward drop-in): channel of slot differs by half
+template <int F, int SLABS, typename Slab>
+__device__ __forceinline__ void load_slots(const float* __restrict__ row, int h, Slab* out) {
+#pragma unroll
+    for (int ks = 0; ks < SLABS; ++ks) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c0 = enc_slot_channel(F, SLABS, ks, 0, j), c1 = enc_slot_channel(F, SLABS, ks, 1, j);
+            const int c = h ? c1 : c0;
+            t8[j] = (c >= 0) ? row[c >= 0 ? c : 0] : 0.0f;
+        }
+        make_slab(out[ks], t8);
+    }
+}
+
+constexpr int MODE_EMBEDDED = 0, MODE_RAYS = 1;
+
+template <int PREC, int MODE, bool SIGMA_ONLY>
+__global__ __launch_bounds__(PrecTraits<PREC>::NW * 64, PrecTraits<PREC>::WPS)
+void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
+                    const uint8_t* __restrict__ packed, float* __restrict__ out) {
+    using Slab = typename PrecTraits<PREC>::Slab;
+    constexpr int NW = PrecTraits<PREC>::NW;
+    constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
+    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int h = lane >> 5;
+    const int64_t p = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    const bool valid = p < n;
+    const int64_t pc = valid ? p : n - 1;
+
+    // ---- raw inputs (ordinary loads, issued before the DMA stream starts) ----
+    float xyz[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f};
+    const float* row = nullptr;
+    if (MODE == MODE_RAYS) {
+        const int64_t S = aux;
+        const int64_t ray = pc / S;
+        const float zv = in1[pc];
+        const float* rp = in0 + ray * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dir[c] = rp[3 + c];
+            xyz[c] = __fadd_rn(rp[c], __fmul_rn(dir[c], zv));   // o + d*z   rendering.py:206-207
+        }
+    } else {
+        row = in0 + pc * aux;
+    }
+
+    WeightStream<PREC, NCH> st;
+    st.gsrc = packed + lane * 16;
+    st.lds_base = (unsigned)(uintptr_t)ring;
+    st.wave = wave;
+    st.issue_chunk(0);
+    if (NCH > 1) st.issue_chunk(1);
+
+    const char* smem_lane = ring + lane * 16;
+    const char* smem_half = ring + h * 16;
+
+    Slab encx[kXyzSlabs];
+    Slab encd[kDirSlabs];
+    if (MODE == MODE_RAYS) {
+        encode_slots<10, kXyzSlabs>(xyz, h, encx);
+        if (!SIGMA_ONLY) encode_slots<4, kDirSlabs>(dir, h, encd);
+    } else {
+        load_slots<10, kXyzSlabs>(row, h, encx);
+        if (!SIGMA_ONLY) load_slots<4, kDirSlabs>(row + kXyzCh, h, encd);
+    }
+
+    f32x16 acc[8];
+    Slab hs[16];
+    run_layer<PREC, 0, NCH, 8>(st, smem_lane, smem_half, encx, (const Slab*)nullptr, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 1, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 2, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 3, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 4, NCH, 8>(st, smem_lane, smem_half, encx, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 5, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 6, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+    run_layer<PREC, 7, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+    to_slabs<true>(acc, hs);
+
+    f32x16 sacc[1];
+    run_layer<PREC, 8, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, sacc);
+    const float sigma = sacc[0][0];                         // row 0 lives in reg 0 of the h=0 lanes
+
+    if (SIGMA_ONLY) {
+        if (valid && h == 0) out[p] = sigma;                // (n,1)   nerf.py:112-114
+        return;
+    } else {
+        run_layer<PREC, 9, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
+        to_slabs<false>(acc, hs);                            // xyz_encoding_final: no activation
+        f32x16 dacc[4];
+        run_layer<PREC, 10, NCH, 4>(st, smem_lane, smem_half, encd, hs, dacc);
+        Slab hd[8];
+        to_slabs<true>(dacc, hd);
+        f32x16 racc[1];
+        run_layer<PREC, 11, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hd, racc);
+        if (valid && h == 0) {
+            float4 o;
+            o.x = 1.0f / (1.0f + expf(-racc[0][0]));        // sigmoid   nerf.py:79-81
+            o.y = 1.0f / (1.0f + expf(-racc[0][1]));
+            o.z = 1.0f / (1.0f + expf(-racc[0][2]));
+            o.w = sigma;                                     // cat([rgb, sigma])   nerf.py:122
+            reinterpret_cast<float4*>(out)[p] = o;
+        }
+    }
+}
+
+template <int PREC, int MODE>
+static int launch_fwd(const float* in0, const float* in1, int64_t n, int64_t aux, const void* packed, float* out,
+                      int sigma_only, hipStream_t stream) {
+    constexpr int NW = PrecTraits<PREC>::NW;
+    const int64_t blocks = (n + 32 * NW - 1) / (32 * NW);
+    if (blocks > 0x7fffffff) return NERFHIP_E_BADARG;
+    dim3 grid((unsigned)blocks), block(NW * 64);
+    if (sigma_only)
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, true>), grid, block, 0, stream, in0, in1, n, aux,
+                           (const uint8_t*)packed, out);
+    else
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false>), grid, block, 0, stream, in0, in1, n, aux,
+                           (const uint8_t*)packed, out);
+    return nerfhip_launch_status();
+}
+
+}  // namespace nerfhip
+
+extern "C" int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const void* packed, float* out,
+                                        int sigma_only, int dtype, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(n >= 0 && x_stride >= (sigma_only ? 63 : 90));
+    if (n == 0) return 0;
+    NERFHIP_CHECK_ARG(x && packed && out);
+    if ((((uintptr_t)packed) & 15) || (!sigma_only && (((uintptr_t)out) & 15))) return NERFHIP_E_ALIGN;
+    if (dtype == NERFHIP_BF16)
+        return nerfhip::launch_fwd<NERFHIP_BF16, nerfhip::MODE_EMBEDDED>(x, nullptr, n, x_stride, packed, out, sigma_only,
+                                                                          (hipStream_t)stream);
+    if (dtype == NERFHIP_F32)
+        return nerfhip::launch_fwd<NERFHIP_F32, nerfhip::MODE_EMBEDDED>(x, nullptr, n, x_stride, packed, out, sigma_only,
+                                                                         (hipStream_t)stream);
+    return NERFHIP_E_UNSUPPORTED;
+}
+
+extern "C" int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, const void* packed, float* out,
+                                    int sigma_only, int dtype, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 1);
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(rays && z && packed && out);
+    if ((((uintptr_t)packed) & 15) || (!sigma_only && (((uintptr_t)out) & 15))) return NERFHIP_E_ALIGN;
+    const int64_t n = B * (int64_t)S;
+    if (dtype == NERFHIP_BF16)
+        return nerfhip::launch_fwd<NERFHIP_BF16, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only,
+                                                                      (hipStream_t)stream);
+    if (dtype == NERFHIP_F32)
+        return nerfhip::launch_fwd<NERFHIP_F32, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only,
+                                                                     (hipStream_t)stream);
+    return NERFHIP_E_UNSUPPORTED;
+}

@@ -1,0 +1,123 @@
+// Packed-weight stream layout of the fused NeRF MLP (reference models/nerf.py:42-124, default
+// architecture D=8, W=256, skips=[4], 63/27 input channels).
+//
+// The kernel keeps the activations of 32 points per wavefront IN REGISTERS for the whole network:
+// the MFMA computes   H_out^T[256 x 32pts] = W[256 x K] * H_in^T[K x 32pts]   with the weights as the
+// A operand and the points as the N dimension, so the C/D fragment of one layer (lane = point,
+// registers = output features) is — after bias/ReLU/(bf16 pack) — directly the B operand of the next
+// layer.  No cross-lane traffic is needed because we choose which 8 input features a lane's B
+// registers mean and permute the COLUMNS of W to match when packing:
+//     C/D layout of v_mfma_f32_32x32x*:  lane l -> col n = l&31, half h = l>>5;
+//                                        reg r  -> row (r&3) + 8*(r>>2) + 4*h     (r in 0..15)
+//     B "slab" ks (16 features) of a 32-row tile t = ks/2, s = ks%2 uses regs 8s..8s+7, i.e.
+//     slot (ks,h,j) <-> feature 16*ks + 8*(j>>2) + 4*h + (j&3).
+// Weights stream through LDS as 1 KiB "pieces" (64 lanes x 16 B, exactly one ds_read_b128 per wave)
+// in the precise order the kernel consumes them, so both the global->LDS DMA and the LDS reads are
+// lane-linear and bank-conflict free.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NH_HD __host__ __device__
+#else
+#define NH_HD
+#endif
+
+namespace nerfhip {
+namespace mlp {
+
+constexpr int kPieceBytes = 1024;
+constexpr int kChunkPieces = 32;                       // 32 KiB per ring slot
+constexpr int kChunkBytes = kPieceBytes * kChunkPieces;
+constexpr int kSlots = 3;                              // LDS ring: 96 KiB
+
+constexpr int kXyzCh = 63, kDirCh = 27, kW = 256;
+constexpr int kXyzSlabs = 4;   // 63 channels (+1 pad) = 64 slots
+constexpr int kDirSlabs = 2;   // 27 channels (+5 pad) = 32 slots
+
+enum InKind { IN_XYZ = 0, IN_CHAIN = 1, IN_XYZ_CHAIN = 2, IN_DIR_CHAIN = 3 };
+
+struct Layer {
+    int param;        // index in state_dict order: 0..7 xyz_encoding_1..8, 8 final, 9 dir, 10 sigma, 11 rgb
+    int nt;           // 32-row output tiles
+    int n_out;        // real output features
+    int kind;         // InKind
+    int enc_slabs;    // leading slabs fed by an input encoding (xyz or dir)
+    int chain_slabs;  // slabs fed by the previous layer's registers
+};
+
+// kernel execution order
+constexpr int kNumLayers = 12;
+constexpr int kSigmaLayer = 8;     // index (in this table) of the sigma head
+constexpr Layer kLayers[kNumLayers] = {
+    {0, 8, 256, IN_XYZ, 4, 0},         // xyz_encoding_1          nerf.py:62-63
+    {1, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_2
+    {2, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_3
+    {3, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_4
+    {4, 8, 256, IN_XYZ_CHAIN, 4, 16},  // xyz_encoding_5 (skip: cat([input_xyz, h]))   nerf.py:64-65,108-109
+    {5, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_6
+    {6, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_7
+    {7, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_8
+    {10, 1, 1, IN_CHAIN, 0, 16},       // sigma (raw)                                   nerf.py:78,112
+    {8, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_final (no activation)            nerf.py:70,116
+    {9, 4, 128, IN_DIR_CHAIN, 2, 16},  // dir_encoding: cat([final, input_dir])         nerf.py:73-75,118
+    {11, 1, 3, IN_CHAIN, 0, 8},        // rgb (sigmoid)                                 nerf.py:79-81
+};
+
+// reference in_features per state_dict entry (row stride of weight matrices)
+constexpr int kParamIn[12] = {63, 256, 256, 256, 319, 256, 256, 256, 256, 283, 256, 128};
+constexpr int kParamOut[12] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 1, 3};
+
+NH_HD constexpr int layer_slabs(int L) { return kLayers[L].enc_slabs + kLayers[L].chain_slabs; }
+// pieces per (slab, tile) fragment: bf16 = 1 (8 x bf16 per lane), fp32 = 2 (8 x f32 per lane)
+NH_HD constexpr int ppf(int prec) { return prec == 0 /*NERFHIP_F32*/ ? 2 : 1; }
+NH_HD constexpr int layer_pieces(int L, int prec) { return 1 + layer_slabs(L) * kLayers[L].nt * ppf(prec); }
+NH_HD constexpr int layer_start(int L, int prec) {
+    int g = 0;
+    for (int i = 0; i < L; ++i) g += layer_pieces(i, prec);
+    return g;
+}
+NH_HD constexpr int total_pieces(int prec) { return layer_start(kNumLayers, prec); }
+NH_HD constexpr int padded_pieces(int prec) {
+    return (total_pieces(prec) + kChunkPieces - 1) / kChunkPieces * kChunkPieces;
+}
+NH_HD constexpr int chunks_upto_layer(int Lend, int prec) {   // chunks needed to run layers [0, Lend)
+    return (layer_start(Lend, prec) + kChunkPieces - 1) / kChunkPieces;
+}
+
+// ---- input-slot maps --------------------------------------------------------------------------
+// Encoding channel (reference order, nerf.py:33-38: [x, sin f0 x, cos f0 x, sin f1 x, ...]) held by
+// slot (ks,h,j) of an encoding with F frequencies spread over `slabs` slabs; -1 = zero padding.
+// Half h owns frequencies k = 2i+h, so one sincos per lane yields both channels it needs;
+// the 3 identity channels fill the tail (h=0: x,y ; h=1: z).
+NH_HD constexpr int enc_slot_channel(int F, int slabs, int ks, int h, int j) {
+    const int idx = 8 * ks + j;                // 0 .. 8*slabs-1 within this half
+    const int npair = 3 * (F / 2);             // (i,c) pairs per half
+    if (idx < 2 * npair) {
+        const int p = idx >> 1, i = p / 3, c = p % 3, k = 2 * i + h;
+        return 3 + 6 * k + c + 3 * (idx & 1);
+    }
+    const int tail = idx - 2 * npair;          // identity channels
+    if (h == 0) return tail < 2 ? tail : -1;
+    return tail == 0 ? 2 : -1;
+}
+NH_HD constexpr int xyz_slot_channel(int ks, int h, int j) { return enc_slot_channel(10, kXyzSlabs, ks, h, j); }
+NH_HD constexpr int dir_slot_channel(int ks, int h, int j) { return enc_slot_channel(4, kDirSlabs, ks, h, j); }
+NH_HD constexpr int chain_feature(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// Column of the reference weight matrix W[out][in] multiplied by slot (ks,h,j) of layer L; -1 = pad.
+NH_HD constexpr int layer_in_col(int L, int ks, int h, int j) {
+    const Layer& ly = kLayers[L];
+    if (ks < ly.enc_slabs) {
+        if (ly.kind == IN_DIR_CHAIN) {
+            const int c = dir_slot_channel(ks, h, j);
+            return c < 0 ? -1 : kW + c;                       // cat([final(256), dir(27)])  nerf.py:118
+        }
+        return xyz_slot_channel(ks, h, j);                    // xyz first in cat([xyz, h])   nerf.py:109
+    }
+    const int f = chain_feature(ks - ly.enc_slabs, h, j);
+    return ly.kind == IN_XYZ_CHAIN ? kXyzCh + f : f;
+}
+
+}  // namespace mlp
+}  // namespace nerfhip

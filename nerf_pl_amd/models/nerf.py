@@ -1,0 +1,100 @@
+"""`models.nerf` of kwea123/nerf_pl, MI355X-native.
+
+Same classes, constructor signatures, attributes and `state_dict` layout as the reference
+(models/nerf.py:4-124) so checkpoints, optimizers and DDP see an ordinary nn.Module; `forward`
+dispatches to the HIP kernels of libnerfhip (posenc / fused MFMA MLP) instead of ATen op chains.
+"""
+import torch
+from torch import nn
+
+from .. import default_mlp_dtype, ops
+
+
+class Embedding(nn.Module):
+    def __init__(self, in_channels, N_freqs, logscale=True):
+        """Embeds x to (x, sin(2^k x), cos(2^k x), ...).  Reference: models/nerf.py:5-19."""
+        super(Embedding, self).__init__()
+        self.N_freqs = N_freqs
+        self.in_channels = in_channels
+        self.funcs = [torch.sin, torch.cos]
+        self.out_channels = in_channels * (len(self.funcs) * N_freqs + 1)
+        if logscale:
+            self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
+        self.logscale = logscale
+
+    def forward(self, x):
+        """x: (B, in_channels) -> (B, out_channels).  Reference: models/nerf.py:21-38.
+        One HIP launch (K1 posenc) instead of 41; channel order identical to the reference."""
+        if not self.logscale:
+            raise NotImplementedError("nerf_pl_amd.Embedding: only logscale=True (the reference's only use, "
+                                      "train.py:34-35) is implemented in the HIP kernel")
+        if x.shape[-1] != self.in_channels:
+            raise ValueError("expected %d input channels" % self.in_channels)
+        lead = x.shape[:-1]
+        out = ops.posenc(x.reshape(-1, self.in_channels).float(), self.N_freqs)
+        return out.reshape(*lead, self.out_channels)
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4]):
+        """Reference: models/nerf.py:42-81 (identical submodule names => identical state_dict keys)."""
+        super(NeRF, self).__init__()
+        self.D = D
+        self.W = W
+        self.in_channels_xyz = in_channels_xyz
+        self.in_channels_dir = in_channels_dir
+        self.skips = skips
+        for i in range(D):
+            if i == 0:
+                layer = nn.Linear(in_channels_xyz, W)
+            elif i in skips:
+                layer = nn.Linear(W + in_channels_xyz, W)
+            else:
+                layer = nn.Linear(W, W)
+            layer = nn.Sequential(layer, nn.ReLU(True))
+            setattr(self, f"xyz_encoding_{i+1}", layer)
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.ReLU(True))
+        self.sigma = nn.Linear(W, 1)
+        self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+        # --- MI355X specifics (not part of state_dict) ---
+        self.mlp_dtype = default_mlp_dtype()    # 'fp32' (parity) | 'bf16' (roofline)
+        self._packed_cache = {}
+
+    # -- fused-kernel plumbing -----------------------------------------------------------------
+    def is_default_arch(self):
+        return (self.D == 8 and self.W == 256 and self.in_channels_xyz == 63 and self.in_channels_dir == 27
+                and list(self.skips) == [4])
+
+    def linears(self):
+        """The 12 nn.Linear modules in ops.PARAM_ORDER."""
+        ls = [getattr(self, f"xyz_encoding_{i+1}")[0] for i in range(self.D)]
+        return ls + [self.xyz_encoding_final, self.dir_encoding[0], self.sigma, self.rgb[0]]
+
+    def flat_params(self):
+        """[w0..w11, b0..b11] (the order autograd Functions take them in)."""
+        ls = self.linears()
+        return [l.weight for l in ls] + [l.bias for l in ls]
+
+    def packed_weights(self, dtype=None):
+        """MFMA-fragment-ordered copy of the parameters, rebuilt only when a parameter changed."""
+        if not self.is_default_arch():
+            raise NotImplementedError("the fused HIP MLP implements the reference's default architecture "
+                                      "(D=8, W=256, skips=[4], 63/27 inputs) only")
+        dtype = dtype or self.mlp_dtype
+        ps = self.flat_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self._packed_cache.get(dtype)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = ops.pack_weights(ps[:12], ps[12:], dtype, out=hit[1] if hit is not None and hit[1].device == ps[0].device else None)
+        self._packed_cache[dtype] = (key, buf)
+        return buf
+
+    def forward(self, x, sigma_only=False):
+        """x: (B, 63+27) embedded position+direction, or (B, 63) when sigma_only.
+        Returns (B,4)=[rgb, sigma] or (B,1) sigma.  Reference: models/nerf.py:83-124."""
+        from .mlp_autograd import mlp_embedded
+        return mlp_embedded(self, x, bool(sigma_only))

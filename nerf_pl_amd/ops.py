@@ -1,0 +1,244 @@
+"""Python-side operators over libnerfhip's C ABI (include/nerfhip.h).
+
+Each function allocates its outputs with torch (torch owns all HBM), passes raw device pointers +
+the current HIP stream through ctypes, and raises `NerfHipError` on any non-zero return.  There is
+no CPU path and no eager-PyTorch fallback: tensors must live on an MI355X.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, NerfHipError, check, ptr, require_gpu, stream_ptr
+
+_DTYPES = {"fp32": F32, "f32": F32, "float32": F32, torch.float32: F32, F32: F32,
+           "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16}
+
+
+def mlp_dtype_code(d):
+    if isinstance(d, bool) or d not in _DTYPES:
+        raise ValueError("mlp dtype must be 'fp32' or 'bf16', got %r" % (d,))
+    return _DTYPES[d]
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------- posenc (a2)
+class _PosEnc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_freqs):
+        require_gpu(x)
+        x = _c(x)
+        n, C = x.shape
+        out = torch.empty(n, C * (2 * n_freqs + 1), device=x.device, dtype=torch.float32)
+        check(_lib.load().nerfhip_posenc(ptr(x), ptr(out), n, C, n_freqs, stream_ptr()), "nerfhip_posenc")
+        ctx.save_for_backward(x)
+        ctx.n_freqs = n_freqs
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        gout = _c(gout.float())
+        gx = torch.empty_like(x)
+        n, C = x.shape
+        check(_lib.load().nerfhip_posenc_bwd(ptr(x), ptr(gout), ptr(gx), n, C, ctx.n_freqs, stream_ptr()),
+              "nerfhip_posenc_bwd")
+        return gx, None
+
+
+def posenc(x, n_freqs):
+    """Embedding.forward (reference models/nerf.py:21-38), logscale bands. x (n,C) -> (n, C(2F+1))."""
+    if x.dim() != 2:
+        raise ValueError("posenc expects (n, C)")
+    return _PosEnc.apply(x, int(n_freqs))
+
+
+# ------------------------------------------------------------------------------- sampling (a5, a8-a10)
+def sample_coarse_z(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
+    """rendering.py:183-204.  rays (B,8) -> z (B,S)."""
+    require_gpu(rays, perturb_rand)
+    rays = _c(rays)
+    B = rays.shape[0]
+    z = torch.empty(B, n_samples, device=rays.device, dtype=torch.float32)
+    if perturb > 0:
+        if perturb_rand is None:
+            raise ValueError("perturb>0 needs perturb_rand")
+        perturb_rand = _c(perturb_rand)
+    check(_lib.load().nerfhip_sample_coarse_z(ptr(rays), ptr(perturb_rand if perturb > 0 else None), ptr(z), B,
+                                              n_samples, int(bool(use_disp)), float(perturb), stream_ptr()),
+          "nerfhip_sample_coarse_z")
+    return z
+
+
+def searchsorted(a, v, out=None, side="left"):
+    """Drop-in for torchsearchsorted.searchsorted (reference models/rendering.py:2,42): batched
+    row-wise numpy-style searchsorted; a (B,M), v (B,K) float32 -> int64 (B,K)."""
+    require_gpu(a, v)
+    if side not in ("left", "right"):
+        raise ValueError("side must be 'left' or 'right'")
+    a, v = _c(a), _c(v)
+    if a.dim() != 2 or v.dim() != 2 or a.shape[0] != v.shape[0]:
+        raise ValueError("searchsorted expects a (B,M) and v (B,K)")
+    B, M = a.shape
+    K = v.shape[1]
+    if out is None:
+        out = torch.empty(B, K, device=a.device, dtype=torch.int64)
+    elif out.dtype != torch.int64 or not out.is_contiguous() or tuple(out.shape) != (B, K):
+        raise ValueError("out must be a contiguous int64 (B,K) tensor")
+    fn = _lib.load().nerfhip_searchsorted_right if side == "right" else _lib.load().nerfhip_searchsorted_left
+    check(fn(ptr(a), ptr(v), ptr(out), B, M, K, stream_ptr()), "nerfhip_searchsorted_" + side)
+    return out
+
+
+def sample_pdf_u(bins, weights, n_importance, u=None, eps=1e-5):
+    """sample_pdf with explicit uniforms: u None -> deterministic linspace; (K,) or (B,K) otherwise."""
+    require_gpu(bins, weights, u)
+    if bins.stride(-1) != 1:
+        bins = bins.contiguous()
+    if weights.stride(-1) != 1:
+        weights = weights.contiguous()
+    B, M = weights.shape
+    if bins.shape != (B, M + 1):
+        raise ValueError("bins must be (N_rays, N_samples_+1)")
+    u_stride = 0
+    if u is not None:
+        u = _c(u)
+        if u.dim() == 2:
+            if u.shape != (B, n_importance):
+                raise ValueError("u must be (B, N_importance)")
+            u_stride = n_importance
+        elif u.shape != (n_importance,):
+            raise ValueError("u must be (N_importance,) or (B, N_importance)")
+    samples = torch.empty(B, n_importance, device=bins.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_sample_pdf(ptr(bins), bins.stride(0), ptr(weights), weights.stride(0), ptr(u), u_stride,
+                                         ptr(samples), B, M, n_importance, float(eps), stream_ptr()),
+          "nerfhip_sample_pdf")
+    return samples
+
+
+def fine_z(z_coarse, w_coarse, n_importance, u=None, eps=1e-5, return_new=False):
+    """rendering.py:223-229 in one launch: z_fine = sort(cat(z_coarse, sample_pdf(z_mid, w[:,1:-1])))."""
+    require_gpu(z_coarse, w_coarse, u)
+    z_coarse, w_coarse = _c(z_coarse), _c(w_coarse)
+    B, S = z_coarse.shape
+    u_stride = 0
+    if u is not None:
+        u = _c(u)
+        u_stride = n_importance if u.dim() == 2 else 0
+    zf = torch.empty(B, S + n_importance, device=z_coarse.device, dtype=torch.float32)
+    zn = torch.empty(B, n_importance, device=z_coarse.device, dtype=torch.float32) if return_new else None
+    check(_lib.load().nerfhip_fine_z(ptr(z_coarse), ptr(w_coarse), ptr(u), u_stride, ptr(zf), ptr(zn), B, S,
+                                     n_importance, float(eps), stream_ptr()), "nerfhip_fine_z")
+    return (zf, zn) if return_new else zf
+
+
+# ------------------------------------------------------------------------------- compositing (a7)
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z, rays, noise, noise_std, white_back):
+        require_gpu(raw, z, rays, noise)
+        raw, z, rays = _c(raw), _c(z), _c(rays)
+        B, S = z.shape
+        raw_ch = 4 if raw.dim() == 3 else 1
+        if raw.numel() != B * S * raw_ch:
+            raise ValueError("raw must be (B,S,4) or (B,S)")
+        if noise is not None:
+            noise = _c(noise)
+        dev = z.device
+        weights = torch.empty(B, S, device=dev, dtype=torch.float32)
+        opacity = torch.empty(B, device=dev, dtype=torch.float32)
+        rgb = torch.empty(B, 3, device=dev, dtype=torch.float32) if raw_ch == 4 else None
+        depth = torch.empty(B, device=dev, dtype=torch.float32) if raw_ch == 4 else None
+        check(_lib.load().nerfhip_composite_fwd(ptr(raw), raw_ch, ptr(z), ptr(rays), ptr(noise), float(noise_std),
+                                                int(bool(white_back)), ptr(weights), ptr(rgb), ptr(depth),
+                                                ptr(opacity), B, S, stream_ptr()), "nerfhip_composite_fwd")
+        ctx.save_for_backward(raw, z, rays, noise)
+        ctx.cfg = (raw_ch, float(noise_std), int(bool(white_back)))
+        if raw_ch == 4:
+            return weights, opacity, rgb, depth
+        return weights, opacity
+
+    @staticmethod
+    def backward(ctx, g_weights, g_opacity, g_rgb=None, g_depth=None):
+        raw, z, rays, noise = ctx.saved_tensors
+        raw_ch, noise_std, white_back = ctx.cfg
+        B, S = z.shape
+
+        def prep(g):
+            return None if g is None else _c(g.float())
+
+        g_raw = torch.empty_like(raw)
+        check(_lib.load().nerfhip_composite_bwd(ptr(raw), raw_ch, ptr(z), ptr(rays), ptr(noise), noise_std, white_back,
+                                                ptr(prep(g_rgb)), ptr(prep(g_depth)), ptr(prep(g_opacity)),
+                                                ptr(prep(g_weights)), ptr(g_raw), B, S, stream_ptr()),
+              "nerfhip_composite_bwd")
+        return g_raw, None, None, None, None, None
+
+
+def composite(raw, z, rays, noise=None, noise_std=0.0, white_back=False):
+    """Volume-rendering quadrature (rendering.py:143-172).
+    raw (B,S,4) -> (weights, opacity, rgb, depth);  raw (B,S) sigma-only -> (weights, opacity)."""
+    if noise_std == 0:
+        noise = None
+    return _Composite.apply(raw, z, rays, noise, float(noise_std), bool(white_back))
+
+
+# ------------------------------------------------------------------------------- MLP (a3, a4, a6)
+PARAM_ORDER = ["xyz_encoding_1.0", "xyz_encoding_2.0", "xyz_encoding_3.0", "xyz_encoding_4.0",
+               "xyz_encoding_5.0", "xyz_encoding_6.0", "xyz_encoding_7.0", "xyz_encoding_8.0",
+               "xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
+PARAM_SHAPES = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (256, 256),
+                (256, 256), (128, 283), (1, 256), (3, 128)]
+
+
+def packed_bytes(dtype):
+    return int(_lib.load().nerfhip_mlp_packed_bytes(mlp_dtype_code(dtype)))
+
+
+def pack_weights(weights, biases, dtype, out=None):
+    """Repack 12 (weight, bias) fp32 tensors (state_dict order, PARAM_ORDER) into the MFMA A-fragment
+    stream of `dtype`.  Returns a uint8 device buffer."""
+    code = mlp_dtype_code(dtype)
+    if len(weights) != 12 or len(biases) != 12:
+        raise ValueError("need 12 weights and 12 biases")
+    keep = []
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        require_gpu(w, b)
+        if tuple(w.shape) != PARAM_SHAPES[i] or tuple(b.shape) != (PARAM_SHAPES[i][0],):
+            raise NerfHipError("fused MLP supports the reference default architecture only "
+                               "(D=8, W=256, skips=[4], in 63/27); got %s for %s" % (tuple(w.shape), PARAM_ORDER[i]))
+        keep.append((_c(w.detach()), _c(b.detach())))
+    dev = keep[0][0].device
+    if out is None:
+        out = torch.empty(packed_bytes(dtype), device=dev, dtype=torch.uint8)
+    wp = (ctypes.c_void_p * 12)(*[k[0].data_ptr() for k in keep])
+    bp = (ctypes.c_void_p * 12)(*[k[1].data_ptr() for k in keep])
+    check(_lib.load().nerfhip_mlp_pack_weights(wp, bp, ptr(out), code, stream_ptr()), "nerfhip_mlp_pack_weights")
+    return out
+
+
+def mlp_fwd_embedded(x, packed, sigma_only, dtype):
+    require_gpu(x)
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.reshape(-1, x.shape[-1]).contiguous()
+    n = x.shape[0]
+    need = 63 if sigma_only else 90
+    if x.shape[1] != need:
+        raise ValueError("NeRF.forward expects %d input channels, got %d" % (need, x.shape[1]))
+    out = torch.empty(n, 1 if sigma_only else 4, device=x.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_mlp_fwd_embedded(ptr(x), x.stride(0), n, ptr(packed), ptr(out), int(bool(sigma_only)),
+                                               mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_fwd_embedded")
+    return out
+
+
+def mlp_fwd_rays(rays, z, packed, sigma_only, dtype):
+    require_gpu(rays, z)
+    rays, z = _c(rays), _c(z)
+    B, S = z.shape
+    out = torch.empty((B, S) if sigma_only else (B, S, 4), device=z.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_mlp_fwd_rays(ptr(rays), ptr(z), B, S, ptr(packed), ptr(out), int(bool(sigma_only)),
+                                           mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_fwd_rays")
+    return out
