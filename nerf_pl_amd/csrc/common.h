@@ -5,7 +5,18 @@
 
 #include "../../include/nerfhip.h"
 
+// hipcc defaults to -ffp-contract=fast for device code.  The reference computes every mul/add as a
+// separately rounded fp32 ATen op, so all arithmetic in this library is compiled with contraction
+// OFF and written with the plain operators below (HIP's __fadd_rn/__fmul_rn wrappers are parsed
+// inside HIP's headers with contraction still on, and fuse again after inlining).
+#pragma clang fp contract(off)
+
 #define NERFHIP_WAVE 64
+
+__device__ __forceinline__ float nh_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float nh_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float nh_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float nh_div(float a, float b) { return a / b; }   // IEEE-correct (hipcc default)
 
 #define NERFHIP_CHECK_ARG(cond) \
     do {                        \

@@ -6,10 +6,6 @@
 // torch-CPU cumprod) chained across 64-sample chunks.
 #include "common.h"
 
-// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
-// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
-#pragma clang fp contract(off)
-
 namespace nerfhip {
 
 struct RayGeom {
@@ -18,7 +14,7 @@ struct RayGeom {
 
 __device__ __forceinline__ float ray_dnorm(const float* __restrict__ rays, int64_t r) {
     const float dx = rays[r * 8 + 3], dy = rays[r * 8 + 4], dz = rays[r * 8 + 5];
-    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));  // :150
+    return sqrtf(nh_add(nh_add(nh_mul(dx, dx), nh_mul(dy, dy)), nh_mul(dz, dz)));  // :150
 }
 
 // per-sample quantities shared by forward and backward
@@ -33,14 +29,14 @@ struct SampleTerms {
 __device__ __forceinline__ SampleTerms sample_terms(float z_i, float z_next, bool last, float dnorm, float sigma,
                                                     float noise) {
     SampleTerms t;
-    const float d = last ? 1e10f : __fsub_rn(z_next, z_i);   // :144-146
-    t.delta = __fmul_rn(d, dnorm);                            // :150
-    const float s = __fadd_rn(sigma, noise);
+    const float d = last ? 1e10f : nh_sub(z_next, z_i);   // :144-146
+    t.delta = nh_mul(d, dnorm);                            // :150
+    const float s = nh_add(sigma, noise);
     t.on = s > 0.0f;
     const float sr = t.on ? s : 0.0f;                         // relu   :155
-    t.e = expf(-__fmul_rn(t.delta, sr));
-    t.alpha = __fsub_rn(1.0f, t.e);
-    t.sh = __fadd_rn(__fsub_rn(1.0f, t.alpha), 1e-10f);       // :157
+    t.e = expf(-nh_mul(t.delta, sr));
+    t.alpha = nh_sub(1.0f, t.e);
+    t.sh = nh_add(nh_sub(1.0f, t.alpha), 1e-10f);       // :157
     return t;
 }
 
@@ -72,7 +68,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
             } else {
                 sigma = raw[r * S + i];
             }
-            if (noise) nz = __fmul_rn(noise[r * S + i], noise_std);   // :152
+            if (noise) nz = nh_mul(noise[r * S + i], noise_std);   // :152
         }
         const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
         const double f = valid ? (double)t.sh : 1.0;
@@ -81,7 +77,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
         if (lane == 0) excl = 1.0;
         const float T = (float)(excl * carry);                        // cumprod(...)[:, :-1]  :158-159
         carry = carry * __shfl(incl, 63, 64);
-        const float w = valid ? __fmul_rn(t.alpha, T) : 0.0f;
+        const float w = valid ? nh_mul(t.alpha, T) : 0.0f;
         if (valid) weights[r * S + i] = w;
         acc_o += w;
         if (RAW_CH == 4) {
@@ -96,7 +92,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     if (lane == 0) {
         opacity[r] = acc_o;                                           // weights.sum(1)  :160
         if (RAW_CH == 4) {
-            const float bg = white_back ? __fsub_rn(1.0f, acc_o) : 0.0f;   // :169-170
+            const float bg = white_back ? nh_sub(1.0f, acc_o) : 0.0f;   // :169-170
             rgb[r * 3 + 0] = acc_r + bg;
             rgb[r * 3 + 1] = acc_g + bg;
             rgb[r * 3 + 2] = acc_b + bg;
@@ -148,7 +144,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             } else {
                 sigma = raw[r * S + i];
             }
-            if (noise) nz = __fmul_rn(noise[r * S + i], noise_std);
+            if (noise) nz = nh_mul(noise[r * S + i], noise_std);
         }
         const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
         const double f = valid ? (double)t.sh : 1.0;
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             const float zi = zr[i];
             const float zn = (i + 1 < S) ? zr[i + 1] : zi;
             const float sigma = (RAW_CH == 4) ? raw[(r * S + i) * 4 + 3] : raw[r * S + i];
-            const float nz = noise ? __fmul_rn(noise[r * S + i], noise_std) : 0.f;
+            const float nz = noise ? nh_mul(noise[r * S + i], noise_std) : 0.f;
             t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
             T = T_s[i];
             gw = gw_s[i];

@@ -12,10 +12,6 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, 8 waves (2 per SIMD) = 256 points / workgroup
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), 4 waves (1 per SIMD) = 128 points / workgroup
 #include "common.h"
-
-// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
-// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
-#pragma clang fp contract(off)
 #include "mlp_layout.h"
 
 namespace nerfhip {
@@ -233,7 +229,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             dir[c] = rp[3 + c];
-            xyz[c] = __fadd_rn(rp[c], __fmul_rn(dir[c], zv));   // o + d*z   rendering.py:206-207
+            xyz[c] = nh_add(rp[c], nh_mul(dir[c], zv));   // o + d*z   rendering.py:206-207
         }
     } else {
         row = in0 + pc * aux;

@@ -5,10 +5,6 @@
 // fully coalesced 16-byte-per-lane burst; nothing is re-read.
 #include "common.h"
 
-// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
-// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
-#pragma clang fp contract(off)
-
 namespace nerfhip {
 
 constexpr int PE_PTS = 64;      // points per workgroup

@@ -10,10 +10,6 @@
 // indices track the CPU oracle.
 #include "common.h"
 
-// hipcc defaults to -ffp-contract=fast for device code; the reference computes mul and add as separate
-// fp32 roundings (eager ATen ops), so fusing them would break bit-tracking of z / xyz / alpha.
-#pragma clang fp contract(off)
-
 namespace nerfhip {
 
 // torch.linspace(0,1,S)[i] in fp32, bit for bit (checked against ATen for S in 7..192): symmetric
@@ -21,17 +17,17 @@ namespace nerfhip {
 // vectorised kernel fuses it) — so [S-1] == 1.0f exactly.
 __device__ __forceinline__ float linspace01(int i, int S) {
     if (S <= 1) return 0.0f;
-    const float step = __fdiv_rn(1.0f, (float)(S - 1));
-    if (i < S / 2) return __fmul_rn(step, (float)i);
+    const float step = nh_div(1.0f, (float)(S - 1));
+    if (i < S / 2) return nh_mul(step, (float)i);
     return __builtin_fmaf(-step, (float)(S - 1 - i), 1.0f);
 }
 
 __device__ __forceinline__ float coarse_z_raw(float near, float far, int i, int S, int use_disp) {
     const float t = linspace01(i, S);
-    const float omt = __fsub_rn(1.0f, t);
-    if (!use_disp) return __fadd_rn(__fmul_rn(near, omt), __fmul_rn(far, t));                  // :191
-    const float a = __fmul_rn(__fdiv_rn(1.0f, near), omt), b = __fmul_rn(__fdiv_rn(1.0f, far), t);  // :193
-    return __fdiv_rn(1.0f, __fadd_rn(a, b));
+    const float omt = nh_sub(1.0f, t);
+    if (!use_disp) return nh_add(nh_mul(near, omt), nh_mul(far, t));                  // :191
+    const float a = nh_mul(nh_div(1.0f, near), omt), b = nh_mul(nh_div(1.0f, far), t);  // :193
+    return nh_div(1.0f, nh_add(a, b));
 }
 
 __global__ __launch_bounds__(256) void sample_coarse_z_kernel(const float* __restrict__ rays,
@@ -47,10 +43,10 @@ __global__ __launch_bounds__(256) void sample_coarse_z_kernel(const float* __res
     if (perturb > 0.0f) {  // :197-204
         const float zl = (i > 0) ? coarse_z_raw(near, far, i - 1, S, use_disp) : zi;
         const float zr = (i < S - 1) ? coarse_z_raw(near, far, i + 1, S, use_disp) : zi;
-        const float lower = (i > 0) ? __fmul_rn(0.5f, __fadd_rn(zl, zi)) : zi;
-        const float upper = (i < S - 1) ? __fmul_rn(0.5f, __fadd_rn(zi, zr)) : zi;
-        const float pr = __fmul_rn(perturb, prand[idx]);
-        zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), pr));
+        const float lower = (i > 0) ? nh_mul(0.5f, nh_add(zl, zi)) : zi;
+        const float upper = (i < S - 1) ? nh_mul(0.5f, nh_add(zi, zr)) : zi;
+        const float pr = nh_mul(perturb, prand[idx]);
+        zi = nh_add(lower, nh_mul(nh_sub(upper, lower), pr));
     }
     z[idx] = zi;
 }
@@ -100,13 +96,13 @@ template <typename WLoad>
 __device__ __forceinline__ void build_cdf_wave(WLoad wload, int M, float eps, float* cdf_s, int lane) {
     // weights + eps, total (fp64 sum of the fp32 terms, rounded once)            rendering.py:29-30
     double part = 0.0;
-    for (int j = lane; j < M; j += 64) part += (double)__fadd_rn(wload(j), eps);
+    for (int j = lane; j < M; j += 64) part += (double)nh_add(wload(j), eps);
     const float total = (float)wave_sum(part);
     // cdf = [0, cumsum(pdf)]                                                      :31-33
     double carry = 0.0;
     for (int j0 = 0; j0 < M; j0 += 64) {
         const int j = j0 + lane;
-        const float pdf = (j < M) ? __fdiv_rn(__fadd_rn(wload(j), eps), total) : 0.0f;
+        const float pdf = (j < M) ? nh_div(nh_add(wload(j), eps), total) : 0.0f;
         const double incl = wave_incl_sum((double)pdf, lane) + carry;
         if (j < M) cdf_s[j + 1] = (float)incl;
         carry = __shfl(incl, 63, 64);
@@ -121,10 +117,10 @@ __device__ __forceinline__ float invert_cdf(const float* cdf_s, const float* bin
     const int above = min(ind, M);                  // :44
     const float cb = cdf_s[below], ca = cdf_s[above];
     const float bb = bins_s[below], ba = bins_s[above];
-    float denom = __fsub_rn(ca, cb);
+    float denom = nh_sub(ca, cb);
     if (denom < eps) denom = 1.0f;                  // :51
-    const float t = __fdiv_rn(__fsub_rn(u, cb), denom);
-    return __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));  // :54
+    const float t = nh_div(nh_sub(u, cb), denom);
+    return nh_add(bb, nh_mul(t, nh_sub(ba, bb)));  // :54
 }
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, int64_t bins_stride,
@@ -148,6 +144,14 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 }
 
 // z_fine = sort(cat(z_coarse, sample_pdf(z_mid, w[:,1:-1], N_i)))        rendering.py:223-229
+// Merge without a sort network: the coarse depths are already non-decreasing, so
+//   rank(coarse i) = i + #{new < zc_i}            = i + prefix-sum over j<=i of hist[j],  hist[ub_k]++
+//   rank(new k)    = ub_k + #{new q before k}      with ub_k = #{coarse <= zn_k} (binary search)
+// and only the new-vs-new count is quadratic (N^2/64 compares per lane, LDS reads 16 B wide, broadcast).
+__device__ __forceinline__ int fine_z_lds_floats(int S, int N) {
+    const int S4 = (S + 3) & ~3, N4 = (N + 3) & ~3;
+    return 3 * S4 + N4 + ((S + 1 + 3) & ~3) + N4;   // zc | cdf | bins | zn | hist | ub
+}
 __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ zc, const float* __restrict__ wc,
                                                       const float* __restrict__ u, int64_t u_stride,
                                                       float* __restrict__ zf, float* __restrict__ znew_out,
@@ -157,13 +161,18 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
     if (r >= B) return;
     const int M = S - 2;                        // number of pdf bins
-    float* zc_s = lds + (size_t)wave * (3 * S + N);
-    float* cdf_s = zc_s + S;                    // M+1 = S-1
-    float* bins_s = cdf_s + S;                  // M+1 = S-1 midpoints
-    float* zn_s = bins_s + S;                   // N new samples
+    const int S4 = (S + 3) & ~3, N4 = (N + 3) & ~3, H4 = (S + 1 + 3) & ~3;
+    float* zc_s = lds + (size_t)wave * fine_z_lds_floats(S, N);
+    float* cdf_s = zc_s + S4;                   // M+1 = S-1
+    float* bins_s = cdf_s + S4;                 // M+1 = S-1 midpoints
+    float* zn_s = bins_s + S4;                  // N new samples, padded with +inf to a multiple of 4
+    int* hist_s = reinterpret_cast<int*>(zn_s + N4);   // S+1 counters
+    int* ub_s = hist_s + H4;                    // N upper bounds
     for (int j = lane; j < S; j += 64) zc_s[j] = zc[r * S + j];
+    for (int j = lane; j <= S; j += 64) hist_s[j] = 0;
+    if (lane < N4 - N) zn_s[N + lane] = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < S - 1; j += 64) bins_s[j] = __fmul_rn(0.5f, __fadd_rn(zc_s[j], zc_s[j + 1]));  // :223
+    for (int j = lane; j < S - 1; j += 64) bins_s[j] = nh_mul(0.5f, nh_add(zc_s[j], zc_s[j + 1]));  // :223
     const float* wrow = wc + r * S + 1;         // weights_coarse[:, 1:-1]          :225
     build_cdf_wave([&](int j) { return wrow[j]; }, M, eps, cdf_s, lane);
     for (int k = lane; k < N; k += 64) {
@@ -171,23 +180,39 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
         const float v = invert_cdf(cdf_s, bins_s, M, uk, eps);
         zn_s[k] = v;
         if (znew_out) znew_out[r * N + k] = v;
+        const int ub = upper_bound(zc_s, S, v);  // #coarse <= v
+        ub_s[k] = ub;
+        atomicAdd(&hist_s[ub], 1);
     }
     __builtin_amdgcn_wave_barrier();
-    // Stable rank merge of the concatenation [zc (sorted) | zn (any order)].  NaNs are not ordered.
     float* out = zf + r * (S + N);
-    for (int i = lane; i < S; i += 64) {        // coarse element i: earlier in cat order => wins ties
-        const float x = zc_s[i];
-        int less = 0;
-        for (int k = 0; k < N; ++k) less += (zn_s[k] < x) ? 1 : 0;
-        // coarse samples are non-decreasing, so #coarse placed before element i is i itself
-        out[i + less] = x;
+    // coarse elements: inclusive prefix of hist
+    int carry = 0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        int c = (i < S) ? hist_s[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(c, o, 64);
+            if (lane >= o) c += t;
+        }
+        c += carry;
+        if (i < S) out[i + c] = zc_s[i];
+        carry = __shfl(c, 63, 64);
     }
+    // new elements: stable rank among the new ones (NaNs are not ordered)
+    const float4* zn4 = reinterpret_cast<const float4*>(zn_s);
     for (int k = lane; k < N; k += 64) {
         const float x = zn_s[k];
-        int rank = upper_bound(zc_s, S, x);     // #coarse <= x
-        for (int q = 0; q < N; ++q) {
-            const float y = zn_s[q];
-            rank += (y < x || (y == x && q < k)) ? 1 : 0;
+        int rank = ub_s[k];
+#pragma unroll 4
+        for (int q4 = 0; q4 < N4 / 4; ++q4) {
+            const float4 y = zn4[q4];
+            const int q = q4 * 4;
+            rank += (y.x < x || (y.x == x && q + 0 < k)) ? 1 : 0;
+            rank += (y.y < x || (y.y == x && q + 1 < k)) ? 1 : 0;
+            rank += (y.z < x || (y.z == x && q + 2 < k)) ? 1 : 0;
+            rank += (y.w < x || (y.w == x && q + 3 < k)) ? 1 : 0;
         }
         out[rank] = x;
     }
@@ -243,11 +268,13 @@ extern "C" int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const 
 extern "C" int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
                               float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
                               nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(B >= 0 && S_c >= 3 && N_i >= 1 && (3 * S_c + N_i) <= 4096);
+    NERFHIP_CHECK_ARG(B >= 0 && S_c >= 3 && N_i >= 1);
+    const int S4 = (S_c + 3) & ~3, N4 = (N_i + 3) & ~3;
+    const size_t per_wave = (size_t)(3 * S4 + N4 + ((S_c + 1 + 3) & ~3) + N4) * sizeof(float);
+    NERFHIP_CHECK_ARG(4 * per_wave <= 65536);
     if (B == 0) return 0;
     NERFHIP_CHECK_ARG(z_coarse && w_coarse && z_fine);
-    hipLaunchKernelGGL(nerfhip::fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256),
-                       (size_t)4 * (3 * S_c + N_i) * sizeof(float), (hipStream_t)stream, z_coarse, w_coarse, u,
-                       u_stride, z_fine, z_new, B, S_c, N_i, eps);
+    hipLaunchKernelGGL(nerfhip::fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 4 * per_wave,
+                       (hipStream_t)stream, z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps);
     return nerfhip_launch_status();
 }
