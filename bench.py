@@ -1,21 +1,25 @@
 """bench.py — rays/sec of the NeRF hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--mode render|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--mode train|render]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of 1024 synthetic rays per GPU with 64 coarse +
-128 importance samples (BASELINE.json configs[2], the configuration the metric is quoted on):
-`render_rays(models, embeddings, rays, 64, False, perturb=1, noise_std=0, 128, chunk, white_back=True)`
-in training mode (coarse rgb evaluated too: 256 full MLP evaluations per ray).  Inputs are resident
-in HBM before the timed region.  Ray batches shard across ranks with no data-path collective
-(weak scaling).  Rank 0 prints ONE JSON line.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1024 synthetic rays
+per GPU, 64 coarse + 128 importance samples, NeRF D=8 W=256 coarse + fine, perturb=1, noise_std=0,
+white background (the README lego recipe).  Inputs are resident in HBM before the timed region.
+
+A step (default `--mode train`) is ONE FULL TRAINING STEP of the reference's NeRFSystem.training_step
+contract: render_rays forward (coarse + fine, 256 MLP evaluations per ray) -> MSE loss + PSNR ->
+backward through compositing and both MLPs -> [N>1: RCCL all-reduce of the gradients] -> Adam step.
+`--mode render` times the forward `render_rays` alone.  Ray batches shard across ranks (weak scaling:
+1024 rays per GPU, like the reference's DDP).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
 import sys
 import time
+from argparse import Namespace
 
 import torch
 
@@ -23,8 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding
-FLOP_PER_POINT_SIGMA = 982528
+FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
@@ -34,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="render", choices=["render"])
+    ap.add_argument("--mode", default="train", choices=["train", "render"])
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=128)
@@ -43,39 +46,59 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(B, S, N, seconds):
+def cpu_baseline(B, S, N, seconds, train):
     """The pinned CPU oracle (torch-CPU restatement of the reference's render_rays, kind='port') timed
     on this node's host cores on the same workload shape; bounded to ~`seconds` of CPU work."""
     from oracle import nerf_oracle as O
     params = [O.make_params(0), O.make_params(1)]
     rays = O.make_rays(0, B, "blender")
+    tgt = torch.rand(B, 3, generator=torch.Generator().manual_seed(0))
     rng = O.draw_rng(0, B, S, N, 1.0)
+    if train:
+        for d in params:
+            for v in d.values():
+                v.requires_grad_(True)
+        opt = torch.optim.Adam([v for d in params for v in d.values()], lr=5e-4)
+
+    def one(rays_, tgt_, rng_):
+        if not train:
+            with torch.no_grad():
+                O.render_rays(params, rays_, S, False, 1.0, 0, N, True, False, rng=rng_)
+            return
+        res = O.render_rays(params, rays_, S, False, 1.0, 0, N, True, False, rng=rng_)
+        loss = O.mse_loss(res, tgt_)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
     ncpu = os.cpu_count() or 1
-    with torch.no_grad():
-        # torch-CPU oversubscribes badly on many-core hosts: pick the fastest of a few thread counts
-        # on a 1/8-size probe (each probe is a fraction of a second), then time the full workload.
-        best, best_t = 1, float("inf")
-        Bp = max(32, B // 8)
-        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
-            torch.set_num_threads(nt)
-            O.render_rays(params, rays[:Bp], S, False, 1.0, 0, N, True, False, rng={k: v[:Bp] for k, v in rng.items()})
-            t0 = time.perf_counter()
-            O.render_rays(params, rays[:Bp], S, False, 1.0, 0, N, True, False, rng={k: v[:Bp] for k, v in rng.items()})
-            t = time.perf_counter() - t0
-            if t < best_t:
-                best, best_t = nt, t
-        torch.set_num_threads(best)
-        O.render_rays(params, rays, S, False, 1.0, 0, N, True, False, rng=rng)  # warm-up
+    # torch-CPU oversubscribes badly on many-core hosts: pick the fastest of a few thread counts on a
+    # 1/8-size probe, then time the full workload with it.
+    best, best_t = 1, float("inf")
+    Bp = max(32, B // 8)
+    sub = {k: v[:Bp] for k, v in rng.items()}
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        one(rays[:Bp], tgt[:Bp], sub)
         t0 = time.perf_counter()
-        reps = 0
-        while True:
-            O.render_rays(params, rays, S, False, 1.0, 0, N, True, False, rng=rng)
-            reps += 1
-            if time.perf_counter() - t0 > seconds or reps >= 50:
-                break
-        dt = time.perf_counter() - t0
+        one(rays[:Bp], tgt[:Bp], sub)
+        t = time.perf_counter() - t0
+        if t < best_t:
+            best, best_t = nt, t
+    torch.set_num_threads(best)
+    one(rays, tgt, rng)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one(rays, tgt, rng)
+        reps += 1
+        if time.perf_counter() - t0 > seconds or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    what = "training step (fwd+loss+bwd+Adam)" if train else "render_rays fwd"
     return {"value": round(B * reps / dt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d reps of oracle.render_rays fwd on %d rays x (%d+%d), torch-CPU fp32, %.1f s" % (reps, B, S, N, dt)}
+            "sample": "%d reps of the oracle's %s on %d rays x (%d+%d), torch-CPU fp32, %.1f s"
+                      % (reps, what, B, S, N, dt)}
 
 
 def main():
@@ -83,36 +106,55 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist = None
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     from oracle import nerf_oracle as O       # only for seeded synthetic inputs + cpu_baseline
     from nerf_pl_amd import ops
-    from nerf_pl_amd.models import Embedding, NeRF, rendering
+    from nerf_pl_amd.models import rendering
     from nerf_pl_amd.models.mlp_autograd import mlp_rays
+    from nerf_pl_amd.parallel import GradSync
+    from nerf_pl_amd.system import NeRFSystem
 
     B, S, N = a.rays, a.n_samples, a.n_importance
-    models = []
-    for i in range(2):
-        m = NeRF()
-        m.load_state_dict(O.make_params(100 + i, 4.0, 0.2))   # random-init architecture, non-trivial density
+    hp = Namespace(N_samples=S, N_importance=N, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32,
+                   loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[2, 4, 8], decay_gamma=0.5, white_back=True)
+    system = NeRFSystem(hp)
+    # random-init weights of the named architecture (identical on every rank = DDP replicas), density head
+    # scaled so that opacity is non-trivial
+    system.nerf_coarse.load_state_dict(O.make_params(100, 4.0, 0.2))
+    system.nerf_fine.load_state_dict(O.make_params(101, 4.0, 0.2))
+    for m in system.models:
         m.mlp_dtype = a.dtype
-        models.append(m.to(dev))
-    emb = [Embedding(3, 10), Embedding(3, 4)]
-    rays = O.make_rays(1234 + rank, B, "blender").to(dev)
+    system = system.to(dev)
+    models, emb = system.models, system.embeddings
+    (opt,), _ = system.configure_optimizers()
+    grad_sync = GradSync(models) if world > 1 else None
+    rays = O.make_rays(1234 + rank, B, "blender").to(dev)     # each rank draws its own batch
+    rgbs = torch.rand(B, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
+    batch = {"rays": rays, "rgbs": rgbs}
     torch.manual_seed(rank)
 
-    def step():
+    def render_step():
         with torch.no_grad():
             return rendering.render_rays(models, emb, rays, S, False, 1.0, 0.0, N, 1024 * 32, True)
 
+    def train_step():
+        out = system.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        if grad_sync is not None:
+            grad_sync.sync()
+        opt.step()
+        return out
+
+    step = train_step if a.mode == "train" else render_step
     for _ in range(a.warmup):
         step()
 
@@ -133,13 +175,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- dominant kernel: fine-pass fused MLP (B x (S+N) points), HIP events on the launch stream ----
-    roof = None
     if rank == 0:
+        extra = {}
+        if a.mode == "train":                                  # forward-only rate of the same workload
+            for _ in range(5):
+                render_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(30):
+                render_step()
+            torch.cuda.synchronize()
+            extra["render_fwd_rays_per_s_per_gpu"] = round(B * 30 / (time.perf_counter() - t1), 1)
+
+        # ---- dominant kernel: fine-pass fused MLP forward (B x (S+N) points); HIP events on the launch
+        # stream (kernels are launched on torch's current stream, which is what torch.cuda.Event times) ----
         with torch.no_grad():
             z = ops.sample_coarse_z(rays, S, False, 0.0)
-            w = torch.rand(B, S, device=dev)
-            zf = ops.fine_z(z, w, N)
+            zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
             for _ in range(5):
                 mlp_rays(models[1], rays, zf, False)
             reps = 30
@@ -153,25 +205,28 @@ def main():
             avg_ms = sum(ms) / len(ms)
         flops = FLOP_PER_POINT_FULL * B * (S + N)
         ach = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "mlp_fwd_kernel<%s,rays,full> %dx%d pts" % (a.dtype, B, S + N),
+        roof = {"bound": "mfma", "kernel": "mlp_fwd_kernel<%s,rays,full> %dx%d points" % (a.dtype, B, S + N),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "min_launch_us": round(ms[0] * 1e3, 2)}
 
-    if rank == 0:
         total_rays = world * B * a.steps
         out = {
-            "metric": "rays/sec (64+128 samples) render_rays forward, train-mode (coarse+fine rgb)",
+            "metric": ("rays/sec (64+128 samples), full training step: render_rays fwd + MSE + bwd + grad all-reduce + Adam"
+                       if a.mode == "train" else
+                       "rays/sec (64+128 samples), render_rays forward only (train-mode: coarse+fine rgb)"),
             "value": round(total_rays / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[2]: %d rays/GPU x (%d+%d) samples, NeRF D8 W256 coarse+fine, "
-                                   "perturb=1 noise_std=0 white_back, %s MFMA MLP" % (B, S, N, a.dtype),
-                       "rays_per_gpu": B, "N_samples": S, "N_importance": N, "parallelism": "ray-sharded x%d" % world},
+            "config": {"workload": "configs[2]: %d rays/GPU x (%d+%d) samples, NeRF D8 W256 coarse+fine, perturb=1 "
+                                   "noise_std=0 white_back, %s MFMA MLP, mode=%s" % (B, S, N, a.dtype, a.mode),
+                       "rays_per_gpu": B, "N_samples": S, "N_importance": N,
+                       "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if world > 1 and a.mode == "train" else "")},
             "roofline": roof,
         }
+        out.update(extra)
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, S, N, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(B, S, N, a.cpu_seconds, a.mode == "train")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -103,17 +103,44 @@ size_t nerfhip_mlp_packed_bytes(int dtype);
 int nerfhip_mlp_pack_weights(const float* const* weights_host, const float* const* biases_host, void* packed,
                              int dtype, nerfhip_stream_t stream);
 
+/* Training: bytes of the saved-activation buffer the forward fills when `save_acts` != NULL
+ * (every B-operand slab of every layer, in register/fragment order; 4.94 KB/point in bf16,
+ * 9.9 KB/point in fp32).  The backward entry points consume it.               */
+size_t nerfhip_mlp_act_bytes(int64_t n_points, int dtype);
+
 /* NeRF.forward(x, sigma_only) on pre-embedded inputs (nerf.py:83-124):
- * x (n, 90 | 63) with row stride x_stride floats -> out (n,4)=[rgb sigma] | (n,1).          */
+ * x (n, 90 | 63) with row stride x_stride floats -> out (n,4)=[rgb sigma] | (n,1).
+ * save_acts: NULL for inference; else a nerfhip_mlp_act_bytes(n,dtype) buffer (sigma_only must be 0). */
 int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const void* packed, float* out,
-                             int sigma_only, int dtype, nerfhip_stream_t stream);
+                             int sigma_only, int dtype, void* save_acts, nerfhip_stream_t stream);
 
 /* Fused `inference` MLP loop (rendering.py:115-141 + 206-207 + nerf.py:21-38): points are
  * generated in-register as o + d*z, encoded (10 / 4 frequencies) and pushed through the MLP;
  * no (n,63)/(n,90) tensor and no repeat_interleave'd dir embedding ever exists in HBM.
  * rays (B,8), z (B,S) -> out (B,S,4) | (B,S) when sigma_only.                               */
 int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, const void* packed, float* out,
-                         int sigma_only, int dtype, nerfhip_stream_t stream);
+                         int sigma_only, int dtype, void* save_acts, nerfhip_stream_t stream);
+
+/* ---- backward of the MLP (autograd mirror of nerf.py:100-124 under train.py:103-117) -----------
+ * Two hand-written phases: the register-resident chain in reverse with W^T streamed
+ * (writes dL/d(pre-activation) slabs into `dys`), then dW = dY^T X with points as the MFMA K
+ * dimension (split-K partial slabs in `dw_workspace`, reduced and un-permuted into the gradients).
+ *   g_out (n,4)  dL/d[rgb sigma];  out (n,4) the forward's output (for sigmoid');
+ *   packed_bwd   nerfhip_mlp_pack_weights_bwd() image of the CURRENT weights;
+ *   acts         buffer the forward filled (save_acts);  dys  nerfhip_mlp_dy_bytes() scratch;
+ *   dw_workspace nerfhip_mlp_dw_workspace_bytes() scratch;
+ *   grad_w_host / grad_b_host: HOST arrays of 12 DEVICE pointers (state_dict order, (out,in) fp32);
+ *   accumulate != 0 adds into them, else overwrites.  No gradient flows to rays / z / x
+ *   (the reference's sampled depths are detached, rendering.py:226; rays carry no grad).            */
+size_t nerfhip_mlp_packed_bwd_bytes(int dtype);
+int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
+                                 nerfhip_stream_t stream);
+size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype);
+int nerfhip_mlp_dw_splits(int64_t n_points, int dtype);
+size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype);
+int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
+                    void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
+                    int accumulate, int dtype, nerfhip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,10 +38,20 @@ SIGNATURES = {
                               _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
     "nerfhip_mlp_packed_bytes": [_int],
     "nerfhip_mlp_pack_weights": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
-    "nerfhip_mlp_fwd_embedded": [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _int, _int, _c_void_p],
-    "nerfhip_mlp_fwd_rays": [_c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _int, _int, _c_void_p],
+    "nerfhip_mlp_act_bytes": [_i64, _int],
+    "nerfhip_mlp_fwd_embedded": [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _int, _int, _c_void_p, _c_void_p],
+    "nerfhip_mlp_fwd_rays": [_c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _int, _int, _c_void_p, _c_void_p],
+    "nerfhip_mlp_packed_bwd_bytes": [_int],
+    "nerfhip_mlp_pack_weights_bwd": [ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
+    "nerfhip_mlp_dy_bytes": [_i64, _int],
+    "nerfhip_mlp_dw_splits": [_i64, _int],
+    "nerfhip_mlp_dw_workspace_bytes": [_i64, _int],
+    "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                        ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
 }
-_RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t}
+_RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t,
+             "nerfhip_mlp_act_bytes": ctypes.c_size_t, "nerfhip_mlp_packed_bwd_bytes": ctypes.c_size_t,
+             "nerfhip_mlp_dy_bytes": ctypes.c_size_t, "nerfhip_mlp_dw_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

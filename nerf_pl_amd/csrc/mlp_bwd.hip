@@ -1,0 +1,582 @@
+// K2b: backward of the fused NeRF MLP (autograd mirror of reference models/nerf.py:100-124 as driven by
+// train.py:103-117 `loss.backward()`).  Two hand-written phases:
+//
+//  A  mlp_bwd_chain  — per 32-point wave tile, the same register-resident chain as the forward, run in
+//     reverse with W^T streamed through the LDS ring:  g_h(l-1) = W_l^T g_a(l),  g_a = g_h * relu'(h)
+//     (masks read from the activations the forward saved).  Emits every dL/d(pre-activation) as slabs in
+//     the forward's fragment order.  MFMA-bound, ~0.93x the forward's MFMA count.
+//  B  mlp_bwd_dw     — dW_l = dY_l^T X_l with the POINTS as the MFMA K dimension.  dY/X tiles are DMA'd
+//     global->LDS in fragment order (lane-linear, no address math) and transposed on the fly by
+//     ds_read_b64_tr_b16 (bf16) so that lane = feature, regs = points; fp32 gathers with ds_read_b32.
+//     A workgroup owns one (layer, point-range) job: wave w = output tile w against all X tiles, fp32
+//     accumulators in registers for the whole range, one partial slab per workgroup; mlp_bwd_reduce sums
+//     the slabs, un-permutes features and writes the (out,in) gradient tensors + biases.
+//     HBM-bound by construction: 2*256*256 FLOP per 2*256*2 B = 128 FLOP/B.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace nerfhip {
+using namespace mlp;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int PREC> struct BwdTraits;
+template <> struct BwdTraits<NERFHIP_BF16> {
+    using Slab = bf16x8;
+    static constexpr int NW = 8, WPS = 2;
+};
+template <> struct BwdTraits<NERFHIP_F32> {
+    using Slab = f32x8;
+    static constexpr int NW = 4, WPS = 1;
+};
+
+__device__ __forceinline__ void mk_slab(bf16x8& s, const float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = (__bf16)v[j];
+}
+__device__ __forceinline__ void mk_slab(f32x8& s, const float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = v[j];
+}
+__device__ __forceinline__ float slab_get(const bf16x8& s, int j) { return (float)s[j]; }
+__device__ __forceinline__ float slab_get(const f32x8& s, int j) { return s[j]; }
+
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// ================================================================================================
+// W^T packing for the chain
+// ================================================================================================
+struct WTable {
+    const float* w[12];
+};
+
+template <int PREC>
+__global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(WTable P, uint8_t* __restrict__ packed) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int m = lane & 31, h = lane >> 5;
+    uint4 outv = make_uint4(0, 0, 0, 0);
+    if (g < bwd_total_pieces(PREC)) {
+        int L = 0, start = 0;
+        while (L + 1 < kNumBwdLayers && g >= start + bwd_layer_pieces(L, PREC)) { start += bwd_layer_pieces(L, PREC); ++L; }
+        const BwdLayer ly = kBwdLayers[L];
+        const int rel = g - start;
+        const int f = rel / ppf(PREC), sub = rel % ppf(PREC);
+        const int ks = f / ly.nt, t = f % ly.nt;
+        const int icol = ly.col0 + 32 * t + m;                     // input feature of W == output row of W^T
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0.0f;
+            if (ly.sigma_slab && ks == ly.nks - 1) {                // sigma head: one real row (W_sigma[0][:])
+                if (h == 0 && j == 0) v[j] = P.w[10][icol];
+            } else {
+                const int o = chain_feature(ks, h, j);
+                if (o < kParamOut[ly.param] && icol < kParamIn[ly.param])
+                    v[j] = P.w[ly.param][(size_t)o * kParamIn[ly.param] + icol];
+            }
+        }
+        if (PREC == NERFHIP_BF16) {
+            bf16x8 p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = (__bf16)v[j];
+            outv = *reinterpret_cast<uint4*>(&p);
+        } else {
+            outv = make_uint4(__float_as_uint(v[4 * sub + 0]), __float_as_uint(v[4 * sub + 1]),
+                              __float_as_uint(v[4 * sub + 2]), __float_as_uint(v[4 * sub + 3]));
+        }
+    }
+    reinterpret_cast<uint4*>(packed + (size_t)g * kPieceBytes)[lane] = outv;
+}
+
+// ================================================================================================
+// Phase A: backward chain
+// ================================================================================================
+template <int PREC>
+struct BwdStream {
+    static constexpr int NW = BwdTraits<PREC>::NW;
+    static constexpr int LPW = kChunkPieces / NW;
+    static constexpr int NCH = bwd_chunks(PREC);
+    const uint8_t* gsrc;
+    unsigned lds_base;
+    int wave;
+    int pending;   // stores issued since the last boundary (constant-folded; see mlp_fwd.hip)
+
+    __device__ __forceinline__ void issue_chunk(int c) const {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int piece = wave + i * NW;
+            glds16b(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
+                    lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
+        }
+    }
+    __device__ __forceinline__ void boundary(int c) {
+        const int n = (c + 1 < NCH ? LPW : 0) + pending;
+        pending = 0;
+#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {
+            NH_WB(0) NH_WB(1) NH_WB(2) NH_WB(3) NH_WB(4) NH_WB(5) NH_WB(6) NH_WB(7) NH_WB(8)
+            NH_WB(12) NH_WB(16) NH_WB(20) NH_WB(24) NH_WB(28) NH_WB(32) NH_WB(36) NH_WB(40) NH_WB(44) NH_WB(48)
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        }
+#undef NH_WB
+        if (c + 2 < NCH) issue_chunk(c + 2);
+    }
+};
+
+template <int PREC, int L, int NT, int NKS, typename Slab>
+__device__ __forceinline__ void run_bwd_layer(BwdStream<PREC>& st, const char* smem_lane, const Slab* gin,
+                                              f32x16 (&acc)[NT]) {
+    constexpr int G0 = bwd_layer_start(L, PREC);
+    constexpr int PPF = ppf(PREC);
+    static_assert(kBwdLayers[L].nt == NT && kBwdLayers[L].nks == NKS, "bwd layer shape mismatch");
+    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const Slab bs = gin[ks];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int g = G0 + (ks * NT + t) * PPF;
+            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
+            if constexpr (PREC == NERFHIP_BF16) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs, acc[t], 0, 0, 0);
+            } else {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
+                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bs[j], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <typename Slab>
+__device__ __forceinline__ Slab load_slab(__amdgpu_buffer_rsrc_t rsrc, int sec, int lane) {
+    Slab s;
+    u32x4* dst = reinterpret_cast<u32x4*>(&s);
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
+    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16 * q, soff, 0);
+    return s;
+}
+template <int PREC, typename Slab>
+__device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_rsrc_t rsrc, int sec, const Slab& s, int lane) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(&s);
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
+    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
+        __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + 16 * q, soff, 0);
+        st.pending += 1;
+    }
+}
+
+// acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(h) read from the saved
+// activation slabs (same register positions), store as dY section, keep as next B operand.
+template <int PREC, bool MASK, int NT, typename Slab>
+__device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t acts,
+                                             int act_sec, __amdgpu_buffer_rsrc_t dys, int dy_sec, Slab* out, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+        float v[8];
+        Slab hsave;
+        if (MASK) hsave = load_slab<Slab>(acts, act_sec + ks, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gv = acc[ks >> 1][8 * (ks & 1) + j];
+            v[j] = MASK ? (slab_get(hsave, j) > 0.0f ? gv : 0.0f) : gv;
+        }
+        mk_slab(out[ks], v);
+        store_slab(st, dys, dy_sec + ks, out[ks], lane);
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(BwdTraits<PREC>::NW * 64, BwdTraits<PREC>::WPS)
+void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ out, int64_t n,
+                          const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
+                          uint8_t* __restrict__ dys_base) {
+    using Slab = typename BwdTraits<PREC>::Slab;
+    constexpr int NW = BwdTraits<PREC>::NW;
+    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    const int64_t p = tile * 32 + (lane & 31);
+    const bool valid = p < n;
+    const int64_t pc = valid ? p : n - 1;
+
+    float4 g = reinterpret_cast<const float4*>(g_out)[pc];
+    const float4 o = reinterpret_cast<const float4*>(out)[pc];
+    if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);               // padded points contribute nothing
+
+    __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(acts_base) + (size_t)tile * kActSlabs * 64 * sizeof(Slab), 0,
+        (int)(kActSlabs * 64 * sizeof(Slab)), 0x00020000);
+    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(
+        dys_base + (size_t)tile * kDySlabs * 64 * sizeof(Slab), 0, (int)(kDySlabs * 64 * sizeof(Slab)), 0x00020000);
+
+    BwdStream<PREC> st;
+    st.gsrc = packed_bwd + lane * 16;
+    st.lds_base = (unsigned)(uintptr_t)ring;
+    st.wave = wave;
+    st.pending = 0;
+    st.issue_chunk(0);
+    st.issue_chunk(1);
+    const char* smem_lane = ring + lane * 16;
+
+    // d sigmoid: g_a_rgb = g_rgb * rgb * (1 - rgb)      (nerf.py:79-81, 120);  sigma is linear (nerf.py:112)
+    float v[8];
+    Slab zero_slab;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    mk_slab(zero_slab, v);
+    Slab g_rgb, g_sig;
+    {
+        const float ga[3] = {g.x * o.x * (1.0f - o.x), g.y * o.y * (1.0f - o.y), g.z * o.z * (1.0f - o.z)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (h == 0 && j < 3) ? ga[j < 3 ? j : 0] : 0.0f;
+        mk_slab(g_rgb, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (h == 0 && j == 0) ? g.w : 0.0f;
+        mk_slab(g_sig, v);
+    }
+    store_slab(st, dys, kDyRgb, g_rgb, lane);
+    store_slab(st, dys, kDyRgb + 1, zero_slab, lane);
+    store_slab(st, dys, kDySigma, g_sig, lane);
+    store_slab(st, dys, kDySigma + 1, zero_slab, lane);
+
+    // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)
+    Slab gd[8];
+    {
+        f32x16 a4[4];
+        run_bwd_layer<PREC, 0, 4, 1>(st, smem_lane, &g_rgb, a4);
+        finish_layer<PREC, true>(st, a4, acts, kActT, dys, kDyDir, gd, lane);
+    }
+    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)
+    f32x16 acc[8];
+    Slab gs[17];
+    run_bwd_layer<PREC, 1, 8, 8>(st, smem_lane, gd, acc);
+    finish_layer<PREC, false>(st, acc, acts, 0, dys, kDyFeat, gs, lane);
+    gs[16] = g_sig;
+    // final^T + sigma^T : g_h8 ; mask with h8
+    run_bwd_layer<PREC, 2, 8, 17>(st, smem_lane, gs, acc);
+    finish_layer<PREC, true>(st, acc, acts, act_h(8), dys, dy_h(8), gs, lane);
+#define NH_BWD(L)                                                                     \
+    run_bwd_layer<PREC, L, 8, 16>(st, smem_lane, gs, acc);                             \
+    finish_layer<PREC, true>(st, acc, acts, act_h(10 - L), dys, dy_h(10 - L), gs, lane);
+    NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
+#undef NH_BWD
+}
+
+// ================================================================================================
+// Phase B: weight gradients
+// ================================================================================================
+struct DwJobTable {
+    DwJob job[kNumDwJobs];
+};
+
+template <int PREC> struct DwTraits;
+template <> struct DwTraits<NERFHIP_BF16> {
+    static constexpr int SPP = 1;            // 1 KiB pieces per slab
+    static constexpr int DEPTH = 4;          // ring stages
+    static constexpr int MAXP = 36;          // max pieces per stage ((16 + 20) slabs)
+};
+template <> struct DwTraits<NERFHIP_F32> {
+    static constexpr int SPP = 2;
+    static constexpr int DEPTH = 2;
+    static constexpr int MAXP = 72;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512, 2)
+void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_t* __restrict__ acts_base,
+                       const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
+    constexpr int SPP = DwTraits<PREC>::SPP, DEPTH = DwTraits<PREC>::DEPTH, MAXP = DwTraits<PREC>::MAXP;
+    constexpr int LPW = (MAXP + 7) / 8;                       // DMA instructions per wave per stage (padded)
+    constexpr int STAGE_BYTES = MAXP * kPieceBytes;
+    constexpr int SLAB_BYTES = SPP * kPieceBytes;
+    __shared__ __attribute__((aligned(1024))) char ring[DEPTH * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int jid = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const DwJob jb = jobs.job[jid];
+    const int n_ot = jb.dy_slabs / 2;
+    const int n_xs = jb.x1_slabs + jb.x2_slabs;
+    const int n_xt = n_xs / 2;
+    const int npieces = (jb.dy_slabs + n_xs) * SPP;
+    const int64_t my_tiles = (ntiles - split + nsplit - 1) / nsplit;   // tiles split, split+nsplit, ...
+    const unsigned lds_base = (unsigned)(uintptr_t)ring;
+
+    // stage image: [dy slabs][x1 slabs][x2 slabs], each slab SPP lane-linear pieces
+    auto issue_stage = [&](int64_t it) {
+        int64_t T = split + (it < my_tiles ? it : my_tiles - 1) * nsplit;   // past the end: re-fetch (keeps counts uniform)
+        if (T >= ntiles) T = ntiles - 1;
+        const uint8_t* abase = acts_base + (size_t)T * kActSlabs * 64 * (16 * SPP);
+        const uint8_t* dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);
+        const unsigned slot = lds_base + (unsigned)((it % DEPTH) * STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            int pi = wave + 8 * i;
+            if (pi >= npieces) pi = npieces - 1;                            // duplicate DMA of the last piece
+            const int sl = pi / SPP, sub = pi % SPP;
+            const uint8_t* src;
+            if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
+            else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP);
+            else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
+            // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
+            // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
+            glds16b(src + (size_t)sub * kPieceBytes + lane * 16, slot + (unsigned)(pi * kPieceBytes));
+        }
+    };
+
+    f32x16 acc[kDwMaxXTiles];
+#pragma unroll
+    for (int x = 0; x < kDwMaxXTiles; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+    float dbacc = 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s) issue_stage(s);
+
+    // per-lane transposing-read geometry (bf16): 16-lane group g reads a [4 points][16 features] tile whose
+    // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
+    // h=b&1, j-half b>>1 of the slab image  [h][point n][8 x bf16].
+    const int grp = lane >> 4, c = lane & 15;
+    const int tr_off = (grp & 1) * SLAB_BYTES + (((c & 3) & 1) * 32 + 8 * (grp >> 1) + (c >> 2)) * 16 + ((c & 3) >> 1) * 8;
+    // fp32 gather geometry: lane (m = l&31, k = l>>5): feature m -> slab m>>4, natural i = m&15 -> (h,j)
+    const int m32 = lane & 31, kk = lane >> 5;
+    const int f32_off = (m32 >> 4) * SLAB_BYTES + (slab_nat_h(m32 & 15) * 32) * 32 + slab_nat_j(m32 & 15) * 4;
+
+    for (int64_t it = 0; it < my_tiles; ++it) {
+        // stage `it` landed (DEPTH-2 younger stages may still fly), everyone done with stage it-1
+        if (DEPTH == 4) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // 2 * LPW(5)
+        else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_stage(it + DEPTH - 1);
+        if (wave < n_ot) {
+            const char* st_base = ring + (it % DEPTH) * STAGE_BYTES;
+            const char* dy_base = st_base + (2 * wave) * SLAB_BYTES;
+            const char* x_base = st_base + jb.dy_slabs * SLAB_BYTES;
+            if constexpr (PREC == NERFHIP_BF16) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                      // two 16-point k-steps per 32-point tile
+                    union { s16x4 h2[2]; bf16x8 v; } a;
+                    a.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 256));
+                    a.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 256 + 64));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dbacc += (float)a.v[j];
+#pragma unroll
+                    for (int x = 0; x < kDwMaxXTiles; ++x) {
+                        if (x < n_xt) {
+                            union { s16x4 h2[2]; bf16x8 v; } b;
+                            b.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 256));
+                            b.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 256 + 64));
+                            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[x], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll 4
+                for (int ks = 0; ks < 16; ++ks) {                  // 2 points per k-step
+                    const int pt = 2 * ks + kk;
+                    const float a = *reinterpret_cast<const float*>(dy_base + f32_off + pt * 32);
+                    dbacc += a;
+#pragma unroll
+                    for (int x = 0; x < kDwMaxXTiles; ++x) {
+                        if (x < n_xt) {
+                            const float b = *reinterpret_cast<const float*>(x_base + 2 * x * SLAB_BYTES + f32_off + pt * 32);
+                            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
+
+    if (wave < n_ot) {
+        float* sl = slabs + (size_t)blockIdx.x * kDwSlabFloats;
+#pragma unroll
+        for (int x = 0; x < kDwMaxXTiles; ++x) {
+            if (x < n_xt) {
+                float* dst = sl + ((size_t)(wave * kDwMaxXTiles + x) * 64 + lane) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
+            }
+        }
+        sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
+    }
+}
+
+struct GradTable {
+    float* w[12];
+    float* b[12];
+};
+
+// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, int nsplit, const float* __restrict__ slabs,
+                                                              GradTable G, int accumulate) {
+    const int jid = blockIdx.y;
+    const DwJob jb = jobs.job[jid];
+    const int n_ot = jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
+    const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
+    const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
+    const int ot = tile / (kDwMaxXTiles + 1), xt = tile % (kDwMaxXTiles + 1);
+    if (ot >= n_ot) return;
+    if (xt == kDwMaxXTiles) {                          // bias: lanes (m,0) + (m,1)
+        const int m = threadIdx.x;
+        if (m < 32) {
+            float s = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float* sl = slabs + (size_t)(jid * nsplit + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
+                s += sl[m] + sl[m + 32];
+            }
+            const int o = 32 * ot + m;
+            if (o < n_out) G.b[jb.param][o] = accumulate ? G.b[jb.param][o] + s : s;
+        }
+        return;
+    }
+    if (xt >= n_xt) return;
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int lane = e >> 4, r = e & 15;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp)
+            s += slabs[(size_t)(jid * nsplit + sp) * kDwSlabFloats + ((size_t)(ot * kDwMaxXTiles + xt) * 64 + lane) * 16 + r];
+        const int h = lane >> 5, ncol = lane & 31;
+        const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int xi = 32 * xt + ncol;
+        int xs = xi >> 4;
+        const int i = xi & 15;
+        int enc, col0;
+        if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
+        else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
+        int col;
+        if (enc == 0) col = col0 + 16 * xs + i;
+        else {
+            const int ch = (enc == 1) ? xyz_slot_channel(xs, slab_nat_h(i), slab_nat_j(i))
+                                      : dir_slot_channel(xs, slab_nat_h(i), slab_nat_j(i));
+            col = ch < 0 ? -1 : col0 + ch;
+        }
+        if (o < n_out && col >= 0 && col < ldw) {
+            float* dst = G.w[jb.param] + (size_t)o * ldw + col;
+            *dst = accumulate ? *dst + s : s;
+        }
+    }
+}
+
+}  // namespace nerfhip
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" size_t nerfhip_mlp_packed_bwd_bytes(int dtype) {
+    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return 0;
+    return (size_t)nerfhip::mlp::bwd_padded_pieces(dtype) * nerfhip::mlp::kPieceBytes;
+}
+
+extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
+                                            nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(weights_host && packed_bwd);
+    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return NERFHIP_E_UNSUPPORTED;
+    if (((uintptr_t)packed_bwd) & 15) return NERFHIP_E_ALIGN;
+    nerfhip::WTable P;
+    for (int i = 0; i < 12; ++i) {
+        NERFHIP_CHECK_ARG(weights_host[i]);
+        P.w[i] = weights_host[i];
+    }
+    const int n = nerfhip::mlp::bwd_padded_pieces(dtype);
+    if (dtype == NERFHIP_BF16)
+        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
+    else
+        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
+    return nerfhip_launch_status();
+}
+
+static int64_t act_tiles(int64_t n_points, int dtype) {
+    const int64_t ppw = 32 * (dtype == NERFHIP_BF16 ? 8 : 4);
+    return (n_points + ppw - 1) / ppw * (ppw / 32);
+}
+
+extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
+    if (n_points < 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
+}
+
+extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {
+    if (n_points <= 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    const int64_t tiles = act_tiles(n_points, dtype);
+    int64_t s = 512 / nerfhip::mlp::kNumDwJobs;               // ~2 workgroups per CU over all jobs
+    if (s > tiles) s = tiles;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype) {
+    const int s = nerfhip_mlp_dw_splits(n_points, dtype);
+    return (size_t)s * nerfhip::mlp::kNumDwJobs * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+}
+
+extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
+                               const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
+                               float* const* grad_b_host, int accumulate, int dtype, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(n >= 0);
+    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return NERFHIP_E_UNSUPPORTED;
+    NERFHIP_CHECK_ARG(grad_w_host && grad_b_host);
+    nerfhip::GradTable G;
+    for (int i = 0; i < 12; ++i) {
+        NERFHIP_CHECK_ARG(grad_w_host[i] && grad_b_host[i]);
+        G.w[i] = grad_w_host[i];
+        G.b[i] = grad_b_host[i];
+    }
+    if (n == 0) return 0;
+    NERFHIP_CHECK_ARG(g_out && out && packed_bwd && acts && dys && dw_workspace);
+    if ((((uintptr_t)g_out) | ((uintptr_t)out) | ((uintptr_t)packed_bwd) | ((uintptr_t)acts) | ((uintptr_t)dys)) & 15)
+        return NERFHIP_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = act_tiles(n, dtype);
+    const int nsplit = nerfhip_mlp_dw_splits(n, dtype);
+    nerfhip::DwJobTable jt;
+    for (int i = 0; i < nerfhip::mlp::kNumDwJobs; ++i) jt.job[i] = nerfhip::mlp::kDwJobs[i];
+    if (dtype == NERFHIP_BF16) {
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16>, dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, out,
+                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nerfhip::mlp::kNumDwJobs * nsplit), dim3(512), 0, s, jt,
+                           nsplit, tiles, (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+    } else {
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, out,
+                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nerfhip::mlp::kNumDwJobs * nsplit), dim3(512), 0, s, jt,
+                           nsplit, tiles, (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+    }
+    hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel, dim3(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs),
+                       dim3(256), 0, s, jt, nsplit, (const float*)dw_workspace, G, accumulate);
+    return nerfhip_launch_status();
+}

@@ -53,13 +53,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-template <int PREC, int NCH>
+template <int PREC, int NCH, bool COUNT_STORES = false>
 struct WeightStream {
     static constexpr int NW = PrecTraits<PREC>::NW;
     static constexpr int LPW = kChunkPieces / NW;   // DMA instructions per wave per chunk
     const uint8_t* gsrc;     // packed + lane*16
     unsigned lds_base;       // LDS byte address of the ring
     int wave;                // wave index in the workgroup (SGPR)
+    int pending;             // vector-memory STORE instructions issued since the last boundary (SAVE variant).
+                             // Straight-line code: the optimiser folds this to a constant at every boundary.
 
     __device__ __forceinline__ void issue_chunk(int c) const {
 #pragma unroll
@@ -70,11 +72,18 @@ struct WeightStream {
         }
     }
     // Called by every wave right before the first piece of chunk c is read.
-    __device__ __forceinline__ void boundary(int c) const {
+    __device__ __forceinline__ void boundary(int c) {
         // (1) my DMAs for chunk c have landed (chunk c+1's may stay in flight), my LDS reads of chunk c-1
         // have returned; (2) barrier: same holds for every wave => chunk c is readable and the slot of
         // chunk c-1 is free; (3) refill that slot with chunk c+2.
-        if (c + 1 < NCH) {
+        // vmcnt retires in issue order and counts stores too: the ops younger than chunk c's DMAs are the
+        // LPW DMAs of chunk c+1 plus the `pending` activation stores issued since the previous boundary
+        // (older stores are waited for as well — harmless).  Under-counting only over-waits.
+        if constexpr (COUNT_STORES) {
+            const int n = (c + 1 < NCH ? LPW : 0) + pending;
+            pending = 0;
+            wait_barrier(n);
+        } else if (c + 1 < NCH) {
             if (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
@@ -82,15 +91,20 @@ struct WeightStream {
         }
         if (c + 2 < NCH) issue_chunk(c + 2);
     }
+    static __device__ __forceinline__ void wait_barrier(int n) {
+#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {   // multiples of 4 above 8 (round DOWN = safe)
+            NH_WB(0) NH_WB(1) NH_WB(2) NH_WB(3) NH_WB(4) NH_WB(5) NH_WB(6) NH_WB(7) NH_WB(8)
+            NH_WB(12) NH_WB(16) NH_WB(20) NH_WB(24) NH_WB(28) NH_WB(32) NH_WB(36) NH_WB(40) NH_WB(44) NH_WB(48)
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        }
+#undef NH_WB
+    }
 };
 
-__device__ __forceinline__ f32x16 mma_frag(f32x16 acc, const bf16x8& a, const bf16x8& b) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-}
-
 // ---- one layer: acc[t] = bias + sum over slabs W_frag(ks,t) * B[ks] -----------------------------
-template <int PREC, int L, int NCH, int NT, typename Slab>
-__device__ __forceinline__ void run_layer(const WeightStream<PREC, NCH>& st, const char* smem_lane,
+template <int PREC, int L, int NCH, int NT, typename Slab, bool CS>
+__device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, CS>& st, const char* smem_lane,
                                           const char* smem_half, const Slab* enc, const Slab* chain,
                                           f32x16 (&acc)[NT]) {
     constexpr Layer ly = kLayers[L];
@@ -153,6 +167,26 @@ __device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out) {
     }
 }
 
+// ---- training: save B-operand slabs in register (fragment) order, one coalesced 16-B store/lane/piece ----
+// Buffer stores through a per-wave descriptor: wave-uniform section offset in an SGPR (soffset), one
+// 32-bit per-lane offset VGPR — no 64-bit address VGPR pairs competing with the accumulators.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int PREC, int NCH, typename Slab, bool CS>
+__device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __amdgpu_buffer_rsrc_t rsrc, int sec,
+                                           const Slab* slabs, int n, int lane) {
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const unsigned soff = (unsigned)((sec + i) * 64 * sizeof(Slab));
+        const u32x4* src = reinterpret_cast<const u32x4*>(&slabs[i]);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
+            __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + 16 * q, soff, 0);
+            st.pending += 1;
+        }
+    }
+}
+
 // ---- input encodings in slot order (mlp_layout.h: enc_slot_channel) -----------------------------
 // computed from the raw 3-vector: half h evaluates frequencies k = 2i+h; one sincos -> two slots
 template <int F, int SLABS, typename Slab>
@@ -202,10 +236,10 @@ __device__ __forceinline__ void load_slots(const float* __restrict__ row, int h,
 
 constexpr int MODE_EMBEDDED = 0, MODE_RAYS = 1;
 
-template <int PREC, int MODE, bool SIGMA_ONLY>
+template <int PREC, int MODE, bool SIGMA_ONLY, bool SAVE>
 __global__ __launch_bounds__(PrecTraits<PREC>::NW * 64, PrecTraits<PREC>::WPS)
 void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
-                    const uint8_t* __restrict__ packed, float* __restrict__ out) {
+                    const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save) {
     using Slab = typename PrecTraits<PREC>::Slab;
     constexpr int NW = PrecTraits<PREC>::NW;
     constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
@@ -235,10 +269,14 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         row = in0 + pc * aux;
     }
 
-    WeightStream<PREC, NCH> st;
+    WeightStream<PREC, NCH, SAVE> st;
     st.gsrc = packed + lane * 16;
     st.lds_base = (unsigned)(uintptr_t)ring;
     st.wave = wave;
+    st.pending = 0;
+    __amdgpu_buffer_rsrc_t tile_base = __builtin_amdgcn_make_buffer_rsrc(
+        SAVE ? save + ((size_t)blockIdx.x * NW + wave) * kActSlabs * 64 * sizeof(Slab) : (uint8_t*)nullptr, 0,
+        SAVE ? (int)(kActSlabs * 64 * sizeof(Slab)) : 0, 0x00020000);
     st.issue_chunk(0);
     if (NCH > 1) st.issue_chunk(1);
 
@@ -255,24 +293,25 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         if (!SIGMA_ONLY) load_slots<4, kDirSlabs>(row + kXyzCh, h, encd);
     }
 
+    if (SAVE) {
+        save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
+        save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
+    }
     f32x16 acc[8];
     Slab hs[16];
-    run_layer<PREC, 0, NCH, 8>(st, smem_lane, smem_half, encx, (const Slab*)nullptr, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 1, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 2, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 3, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 4, NCH, 8>(st, smem_lane, smem_half, encx, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 5, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 6, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
-    run_layer<PREC, 7, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-    to_slabs<true>(acc, hs);
+#define NH_LAYER(L, ENC, CHAIN)                                                          \
+    run_layer<PREC, L, NCH, 8>(st, smem_lane, smem_half, ENC, CHAIN, acc);                \
+    to_slabs<true>(acc, hs);                                                             \
+    if (SAVE) save_slabs(st, tile_base, act_h(L + 1), hs, 16, lane);
+    NH_LAYER(0, encx, (const Slab*)nullptr)
+    NH_LAYER(1, (const Slab*)nullptr, hs)
+    NH_LAYER(2, (const Slab*)nullptr, hs)
+    NH_LAYER(3, (const Slab*)nullptr, hs)
+    NH_LAYER(4, encx, hs)
+    NH_LAYER(5, (const Slab*)nullptr, hs)
+    NH_LAYER(6, (const Slab*)nullptr, hs)
+    NH_LAYER(7, (const Slab*)nullptr, hs)
+#undef NH_LAYER
 
     f32x16 sacc[1];
     run_layer<PREC, 8, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, sacc);
@@ -284,10 +323,12 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     } else {
         run_layer<PREC, 9, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
         to_slabs<false>(acc, hs);                            // xyz_encoding_final: no activation
+        if (SAVE) save_slabs(st, tile_base, kActFeat, hs, 16, lane);
         f32x16 dacc[4];
         run_layer<PREC, 10, NCH, 4>(st, smem_lane, smem_half, encd, hs, dacc);
         Slab hd[8];
         to_slabs<true>(dacc, hd);
+        if (SAVE) save_slabs(st, tile_base, kActT, hd, 8, lane);
         f32x16 racc[1];
         run_layer<PREC, 11, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hd, racc);
         if (valid && h == 0) {
@@ -303,49 +344,60 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 
 template <int PREC, int MODE>
 static int launch_fwd(const float* in0, const float* in1, int64_t n, int64_t aux, const void* packed, float* out,
-                      int sigma_only, hipStream_t stream) {
+                      int sigma_only, void* save, hipStream_t stream) {
     constexpr int NW = PrecTraits<PREC>::NW;
     const int64_t blocks = (n + 32 * NW - 1) / (32 * NW);
     if (blocks > 0x7fffffff) return NERFHIP_E_BADARG;
     dim3 grid((unsigned)blocks), block(NW * 64);
-    if (sigma_only)
-        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, true>), grid, block, 0, stream, in0, in1, n, aux,
-                           (const uint8_t*)packed, out);
+    if (save) {
+        if (sigma_only) return NERFHIP_E_UNSUPPORTED;
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false, true>), grid, block, 0, stream, in0, in1, n, aux,
+                           (const uint8_t*)packed, out, (uint8_t*)save);
+    } else if (sigma_only)
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, true, false>), grid, block, 0, stream, in0, in1, n, aux,
+                           (const uint8_t*)packed, out, (uint8_t*)nullptr);
     else
-        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false>), grid, block, 0, stream, in0, in1, n, aux,
-                           (const uint8_t*)packed, out);
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false, false>), grid, block, 0, stream, in0, in1, n, aux,
+                           (const uint8_t*)packed, out, (uint8_t*)nullptr);
     return nerfhip_launch_status();
 }
 
 }  // namespace nerfhip
 
+extern "C" size_t nerfhip_mlp_act_bytes(int64_t n_points, int dtype) {
+    if (n_points < 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    const int64_t ppw = 32 * (dtype == NERFHIP_BF16 ? 8 : 4);                 // points per workgroup
+    const int64_t tiles = (n_points + ppw - 1) / ppw * (ppw / 32);             // whole workgroups are written
+    return (size_t)tiles * nerfhip::mlp::kActSlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
+}
+
 extern "C" int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const void* packed, float* out,
-                                        int sigma_only, int dtype, nerfhip_stream_t stream) {
+                                        int sigma_only, int dtype, void* save_acts, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n >= 0 && x_stride >= (sigma_only ? 63 : 90));
     if (n == 0) return 0;
     NERFHIP_CHECK_ARG(x && packed && out);
     if ((((uintptr_t)packed) & 15) || (!sigma_only && (((uintptr_t)out) & 15))) return NERFHIP_E_ALIGN;
     if (dtype == NERFHIP_BF16)
         return nerfhip::launch_fwd<NERFHIP_BF16, nerfhip::MODE_EMBEDDED>(x, nullptr, n, x_stride, packed, out, sigma_only,
-                                                                          (hipStream_t)stream);
+                                                                          save_acts, (hipStream_t)stream);
     if (dtype == NERFHIP_F32)
         return nerfhip::launch_fwd<NERFHIP_F32, nerfhip::MODE_EMBEDDED>(x, nullptr, n, x_stride, packed, out, sigma_only,
-                                                                         (hipStream_t)stream);
+                                                                         save_acts, (hipStream_t)stream);
     return NERFHIP_E_UNSUPPORTED;
 }
 
 extern "C" int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, const void* packed, float* out,
-                                    int sigma_only, int dtype, nerfhip_stream_t stream) {
+                                    int sigma_only, int dtype, void* save_acts, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(B >= 0 && S >= 1);
     if (B == 0) return 0;
     NERFHIP_CHECK_ARG(rays && z && packed && out);
     if ((((uintptr_t)packed) & 15) || (!sigma_only && (((uintptr_t)out) & 15))) return NERFHIP_E_ALIGN;
     const int64_t n = B * (int64_t)S;
     if (dtype == NERFHIP_BF16)
-        return nerfhip::launch_fwd<NERFHIP_BF16, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only,
+        return nerfhip::launch_fwd<NERFHIP_BF16, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only, save_acts,
                                                                       (hipStream_t)stream);
     if (dtype == NERFHIP_F32)
-        return nerfhip::launch_fwd<NERFHIP_F32, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only,
+        return nerfhip::launch_fwd<NERFHIP_F32, nerfhip::MODE_RAYS>(rays, z, n, S, packed, out, sigma_only, save_acts,
                                                                      (hipStream_t)stream);
     return NERFHIP_E_UNSUPPORTED;
 }

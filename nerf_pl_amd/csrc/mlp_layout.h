@@ -119,5 +119,94 @@ NH_HD constexpr int layer_in_col(int L, int ks, int h, int j) {
     return ly.kind == IN_XYZ_CHAIN ? kXyzCh + f : f;
 }
 
+// ================================================================================================
+// Training: saved-activation block, backward chain stream, weight-gradient jobs
+// ================================================================================================
+// Forward (SAVE variant) stores, per 32-point wave tile, every B-operand slab it builds, exactly as
+// held in registers: slab s of tile T lives at  ((T*kActSlabs + s)*64 + lane) * sizeof(Slab)
+// (bf16: 16 B/lane = one 1 KiB piece; fp32: 32 B/lane).  4.94 KB/point in bf16.
+constexpr int kActEncX = 0;                 // 4 slabs  xyz encoding (slot order)
+constexpr int kActEncD = 4;                 // 2 slabs  dir encoding
+constexpr int kActH0 = 6;                   // h1..h8: 8 x 16 slabs (post-ReLU)
+NH_HD constexpr int act_h(int l) { return kActH0 + 16 * (l - 1); }   // l = 1..8
+constexpr int kActFeat = kActH0 + 128;      // 16 slabs  xyz_encoding_final output (no activation)
+constexpr int kActT = kActFeat + 16;        // 8 slabs   dir_encoding output (post-ReLU)
+constexpr int kActSlabs = kActT + 8;        // 158
+
+// Backward chain writes dL/d(pre-activation) slabs in the same format.
+constexpr int kDyRgb = 0;                   // 2 slabs (3 real features, rest zero)
+constexpr int kDyDir = 2;                   // 8 slabs
+constexpr int kDyFeat = 10;                 // 16 slabs
+constexpr int kDySigma = 26;                // 2 slabs (1 real feature)
+constexpr int kDyH0 = 28;                   // dY_8 .. dY_1: 8 x 16 slabs
+NH_HD constexpr int dy_h(int l) { return kDyH0 + 16 * (8 - l); }     // l = 1..8
+constexpr int kDySlabs = kDyH0 + 128;       // 156
+
+// ---- backward chain: g_in = W^T g_out, W^T streamed as A operand ---------------------------------
+struct BwdLayer {
+    int param;      // W of this state_dict entry
+    int nt;         // output tiles (input features of W / 32)
+    int nks;        // slabs of g_out consumed
+    int col0;       // first column of W used as output feature 0 (63 for the skip layer)
+    int sigma_slab; // 1: the last slab is the sigma-head slab (W_sigma row 0 at slot h=0,j=0)
+};
+constexpr int kNumBwdLayers = 10;
+constexpr BwdLayer kBwdLayers[kNumBwdLayers] = {
+    {11, 4, 1, 0, 0},    // rgb^T      : g_a_rgb(3)   -> g_t(128)
+    {9, 8, 8, 0, 0},     // dir^T      : g_a_dir(128) -> g_feat(256)       (feat columns 0..255 of W_dir)
+    {8, 8, 17, 0, 1},    // final^T+sigma^T : [g_feat(256) | g_sigma(1)] -> g_h8(256)
+    {7, 8, 16, 0, 0},    // L8^T : g_a8 -> g_h7
+    {6, 8, 16, 0, 0},    // L7^T
+    {5, 8, 16, 0, 0},    // L6^T
+    {4, 8, 16, 63, 0},   // L5^T : hidden columns 63..318 of W_5 (skip)   nerf.py:109
+    {3, 8, 16, 0, 0},    // L4^T
+    {2, 8, 16, 0, 0},    // L3^T
+    {1, 8, 16, 0, 0},    // L2^T : g_a2 -> g_h1
+};
+NH_HD constexpr int bwd_layer_pieces(int L, int prec) { return kBwdLayers[L].nks * kBwdLayers[L].nt * ppf(prec); }
+NH_HD constexpr int bwd_layer_start(int L, int prec) {
+    int g = 0;
+    for (int i = 0; i < L; ++i) g += bwd_layer_pieces(i, prec);
+    return g;
+}
+NH_HD constexpr int bwd_total_pieces(int prec) { return bwd_layer_start(kNumBwdLayers, prec); }
+NH_HD constexpr int bwd_padded_pieces(int prec) {
+    return (bwd_total_pieces(prec) + kChunkPieces - 1) / kChunkPieces * kChunkPieces;
+}
+NH_HD constexpr int bwd_chunks(int prec) { return bwd_padded_pieces(prec) / kChunkPieces; }
+
+// ---- weight-gradient jobs: dW[o][i] = sum_p dY[p][o] * X[p][i] ------------------------------------
+// One job = one (dY section, X sections) pair; a workgroup's wave w owns output tile w (32 dY features)
+// against all X tiles.  X = [x1 | x2] slabs (x2 may be empty); columns map back to the reference
+// weight matrix through (x?_col0, x?_enc): enc 0 = chain features (natural), 1 = xyz slots, 2 = dir slots.
+struct DwJob {
+    int param;
+    int dy_off, dy_slabs;       // section in the dY block (slabs)
+    int x1_off, x1_slabs, x1_col0, x1_enc;
+    int x2_off, x2_slabs, x2_col0, x2_enc;
+};
+constexpr int kNumDwJobs = 12;
+constexpr DwJob kDwJobs[kNumDwJobs] = {
+    {0, dy_h(1), 16, kActEncX, 4, 0, 1, 0, 0, 0, 0},                 // xyz_encoding_1 : X = enc_xyz
+    {1, dy_h(2), 16, act_h(1), 16, 0, 0, 0, 0, 0, 0},
+    {2, dy_h(3), 16, act_h(2), 16, 0, 0, 0, 0, 0, 0},
+    {3, dy_h(4), 16, act_h(3), 16, 0, 0, 0, 0, 0, 0},
+    {4, dy_h(5), 16, kActEncX, 4, 0, 1, act_h(4), 16, 63, 0},        // skip: [enc_xyz | h4]
+    {5, dy_h(6), 16, act_h(5), 16, 0, 0, 0, 0, 0, 0},
+    {6, dy_h(7), 16, act_h(6), 16, 0, 0, 0, 0, 0, 0},
+    {7, dy_h(8), 16, act_h(7), 16, 0, 0, 0, 0, 0, 0},
+    {8, kDyFeat, 16, act_h(8), 16, 0, 0, 0, 0, 0, 0},                // xyz_encoding_final
+    {9, kDyDir, 8, kActEncD, 2, 256, 2, kActFeat, 16, 0, 0},         // dir_encoding: [enc_dir | feat]
+    {10, kDySigma, 2, act_h(8), 16, 0, 0, 0, 0, 0, 0},               // sigma
+    {11, kDyRgb, 2, kActT, 8, 0, 0, 0, 0, 0, 0},                     // rgb
+};
+constexpr int kDwMaxXTiles = 10;            // (4+16)/2
+// fp32 partial-sum slab of one (job, split): [8 o-tiles][10 x-tiles][64 lanes][16] weights + [8][64] bias
+constexpr int kDwSlabFloats = 8 * kDwMaxXTiles * 64 * 16 + 8 * 64;
+
+// natural feature index i (0..15) inside a slab  <->  slot (h, j)   (chain_feature with ks = 0)
+NH_HD constexpr int slab_nat_h(int i) { return (i >> 2) & 1; }
+NH_HD constexpr int slab_nat_j(int i) { return (i & 3) + 4 * (i >> 3); }
+
 }  // namespace mlp
 }  // namespace nerfhip

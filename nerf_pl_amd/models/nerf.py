@@ -93,6 +93,18 @@ class NeRF(nn.Module):
         self._packed_cache[dtype] = (key, buf)
         return buf
 
+    def packed_weights_bwd(self, dtype=None):
+        """W^T stream for the backward chain, cached like packed_weights()."""
+        dtype = dtype or self.mlp_dtype
+        ps = self.flat_params()[:12]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self._packed_cache.get(("bwd", dtype))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = ops.pack_weights_bwd(ps, dtype, out=hit[1] if hit is not None and hit[1].device == ps[0].device else None)
+        self._packed_cache[("bwd", dtype)] = (key, buf)
+        return buf
+
     def forward(self, x, sigma_only=False):
         """x: (B, 63+27) embedded position+direction, or (B, 63) when sigma_only.
         Returns (B,4)=[rgb, sigma] or (B,1) sigma.  Reference: models/nerf.py:83-124."""

@@ -220,7 +220,12 @@ def pack_weights(weights, biases, dtype, out=None):
     return out
 
 
-def mlp_fwd_embedded(x, packed, sigma_only, dtype):
+def alloc_acts(n_points, dtype, device):
+    nbytes = int(_lib.load().nerfhip_mlp_act_bytes(int(n_points), mlp_dtype_code(dtype)))
+    return torch.empty(nbytes, device=device, dtype=torch.uint8)
+
+
+def mlp_fwd_embedded(x, packed, sigma_only, dtype, save=None):
     require_gpu(x)
     if x.dim() != 2 or x.stride(1) != 1:
         x = x.reshape(-1, x.shape[-1]).contiguous()
@@ -230,15 +235,58 @@ def mlp_fwd_embedded(x, packed, sigma_only, dtype):
         raise ValueError("NeRF.forward expects %d input channels, got %d" % (need, x.shape[1]))
     out = torch.empty(n, 1 if sigma_only else 4, device=x.device, dtype=torch.float32)
     check(_lib.load().nerfhip_mlp_fwd_embedded(ptr(x), x.stride(0), n, ptr(packed), ptr(out), int(bool(sigma_only)),
-                                               mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_fwd_embedded")
+                                               mlp_dtype_code(dtype), ptr(save), stream_ptr()),
+          "nerfhip_mlp_fwd_embedded")
     return out
 
 
-def mlp_fwd_rays(rays, z, packed, sigma_only, dtype):
+def mlp_fwd_rays(rays, z, packed, sigma_only, dtype, save=None):
     require_gpu(rays, z)
     rays, z = _c(rays), _c(z)
     B, S = z.shape
     out = torch.empty((B, S) if sigma_only else (B, S, 4), device=z.device, dtype=torch.float32)
     check(_lib.load().nerfhip_mlp_fwd_rays(ptr(rays), ptr(z), B, S, ptr(packed), ptr(out), int(bool(sigma_only)),
-                                           mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_fwd_rays")
+                                           mlp_dtype_code(dtype), ptr(save), stream_ptr()), "nerfhip_mlp_fwd_rays")
     return out
+
+
+# ------------------------------------------------------------------------------- MLP backward (K2b)
+def pack_weights_bwd(weights, dtype, out=None):
+    """W^T A-fragment stream for the backward chain (12 weights, state_dict order)."""
+    code = mlp_dtype_code(dtype)
+    keep = [_c(w.detach()) for w in weights]
+    for w in keep:
+        require_gpu(w)
+    if out is None:
+        out = torch.empty(int(_lib.load().nerfhip_mlp_packed_bwd_bytes(code)), device=keep[0].device, dtype=torch.uint8)
+    wp = (ctypes.c_void_p * 12)(*[k.data_ptr() for k in keep])
+    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), code, stream_ptr()), "nerfhip_mlp_pack_weights_bwd")
+    return out
+
+
+def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
+    """Gradients of all 24 parameter tensors given dL/d(out).  Returns ([gw0..gw11], [gb0..gb11])."""
+    require_gpu(g_out, out)
+    code = mlp_dtype_code(dtype)
+    g_out = _c(g_out.float()).reshape(-1, 4)
+    out = _c(out).reshape(-1, 4)
+    n = out.shape[0]
+    dev = out.device
+    lib = _lib.load()
+    dys = torch.empty(int(lib.nerfhip_mlp_dy_bytes(n, code)), device=dev, dtype=torch.uint8)
+    ws = torch.empty(int(lib.nerfhip_mlp_dw_workspace_bytes(n, code)), device=dev, dtype=torch.uint8)
+    # one flat fp32 buffer for all 24 gradients (595,844 floats): autograd adopts the views as p.grad,
+    # so a model's gradients are contiguous => ONE RCCL all-reduce per model, no flatten copies
+    sizes = [s[0] * s[1] for s in shapes] + [s[0] for s in shapes]
+    flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(flat[off:off + sz])
+        off += sz
+    gw = [v.view(s) for v, s in zip(views[:12], shapes)]
+    gb = views[12:]
+    gwp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in gw])
+    gbp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in gb])
+    check(lib.nerfhip_mlp_bwd(ptr(g_out), ptr(out), n, ptr(packed_bwd), ptr(acts), ptr(dys), ptr(ws), gwp, gbp, 0, code,
+                              stream_ptr()), "nerfhip_mlp_bwd")
+    return gw, gb, flat

@@ -1,0 +1,127 @@
+"""`NeRFSystem` — the reference's LightningModule (train.py:27-148) over the MI355X-native renderer.
+
+Same attribute names, `forward` chunk loop, `training_step` / `validation_step` /
+`validation_epoch_end` return contracts and optimizer recipe, so the reference's `train.py` logic is
+unchanged; it subclasses pytorch_lightning.LightningModule when that package exists and plain
+nn.Module otherwise (Lightning is not installed in this image; `fit()` below is a 30-line stand-in
+for Trainer.fit used by tests and bench — harness, not product).
+Datasets are injected (`train_dataset` / `val_dataset`): dataset I/O is out of scope.
+"""
+from collections import defaultdict
+
+import torch
+from torch import nn
+
+from .losses import loss_dict
+from .metrics import psnr
+from .models.nerf import Embedding, NeRF
+from .models.rendering import render_rays
+
+try:  # pragma: no cover - not installed here
+    from pytorch_lightning import LightningModule as _Base
+except Exception:  # noqa: BLE001
+    _Base = nn.Module
+
+
+def get_learning_rate(optimizer):
+    for g in optimizer.param_groups:
+        return g['lr']
+
+
+class NeRFSystem(_Base):
+    def __init__(self, hparams, train_dataset=None, val_dataset=None):
+        super(NeRFSystem, self).__init__()
+        self.hparams_ = hparams
+        try:
+            self.hparams = hparams
+        except Exception:  # newer Lightning makes hparams read-only
+            pass
+        self.loss = loss_dict[getattr(hparams, 'loss_type', 'mse')]()
+        self.embedding_xyz = Embedding(3, 10)
+        self.embedding_dir = Embedding(3, 4)
+        self.embeddings = [self.embedding_xyz, self.embedding_dir]
+        self.nerf_coarse = NeRF()
+        self.models = [self.nerf_coarse]
+        if hparams.N_importance > 0:
+            self.nerf_fine = NeRF()
+            self.models += [self.nerf_fine]
+        self.train_dataset = train_dataset
+        self.val_dataset = val_dataset
+        self.white_back = getattr(train_dataset, 'white_back', getattr(hparams, 'white_back', False))
+
+    @property
+    def hp(self):
+        return self.hparams_
+
+    def decode_batch(self, batch):
+        return batch['rays'], batch['rgbs']
+
+    def forward(self, rays):
+        """Batched inference on rays in chunks (train.py:49-71)."""
+        B = rays.shape[0]
+        hp = self.hp
+        results = defaultdict(list)
+        for i in range(0, B, hp.chunk):
+            rendered = render_rays(self.models, self.embeddings, rays[i:i + hp.chunk], hp.N_samples, hp.use_disp,
+                                   hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, self.white_back)
+            for k, v in rendered.items():
+                results[k] += [v]
+        for k, v in results.items():
+            results[k] = torch.cat(v, 0) if len(v) > 1 else v[0]
+        return results
+
+    def configure_optimizers(self):
+        """Adam(lr, eps=1e-8, weight_decay) over all models + MultiStepLR (utils/__init__.py:10-53)."""
+        hp = self.hp
+        params = [p for m in self.models for p in m.parameters()]
+        self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0),
+                                          fused=params[0].is_cuda)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(getattr(hp, 'decay_step', [20])),
+                                                         gamma=getattr(hp, 'decay_gamma', 0.1))
+        return [self.optimizer], [scheduler]
+
+    def training_step(self, batch, batch_nb):
+        """train.py:103-117."""
+        log = {'lr': get_learning_rate(self.optimizer)}
+        rays, rgbs = self.decode_batch(batch)
+        results = self(rays)
+        log['train/loss'] = loss = self.loss(results, rgbs)
+        typ = 'fine' if 'rgb_fine' in results else 'coarse'
+        with torch.no_grad():
+            psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
+            log['train/psnr'] = psnr_
+        return {'loss': loss, 'progress_bar': {'train_psnr': psnr_}, 'log': log}
+
+    def validation_step(self, batch, batch_nb):
+        """train.py:119-138 (image logging omitted: harness concern)."""
+        rays, rgbs = self.decode_batch(batch)
+        rays, rgbs = rays.squeeze(), rgbs.squeeze()
+        results = self(rays)
+        log = {'val_loss': self.loss(results, rgbs)}
+        typ = 'fine' if 'rgb_fine' in results else 'coarse'
+        log['val_psnr'] = psnr(results[f'rgb_{typ}'], rgbs)
+        return log
+
+    def validation_epoch_end(self, outputs):
+        mean_loss = torch.stack([x['val_loss'] for x in outputs]).mean()
+        mean_psnr = torch.stack([x['val_psnr'] for x in outputs]).mean()
+        return {'progress_bar': {'val_loss': mean_loss, 'val_psnr': mean_psnr},
+                'log': {'val/loss': mean_loss, 'val/psnr': mean_psnr}}
+
+
+def fit(system, batches, grad_sync=None, steps=None):
+    """Minimal stand-in for Trainer.fit: configure_optimizers -> per batch training_step, backward,
+    (gradient all-reduce), optimizer.step.  Returns the list of training_step outputs' losses."""
+    (opt,), _ = system.configure_optimizers()
+    losses = []
+    for i, batch in enumerate(batches):
+        if steps is not None and i >= steps:
+            break
+        out = system.training_step(batch, i)
+        opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        if grad_sync is not None:
+            grad_sync.sync()
+        opt.step()
+        losses.append(out['loss'].detach())
+    return losses

@@ -1,0 +1,50 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import nerf_oracle as O
+from tests.helpers import build_models
+dev = torch.device("cuda:0")
+n = 1000
+g = torch.Generator().manual_seed(n)
+p = O.make_params(21, 3.0, 0.1)
+pts = torch.rand(n, 3, generator=g) * 4 - 2
+dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+x = torch.cat([O.posenc(pts, 10), O.posenc(dirs, 4)], 1)
+g_out = torch.randn(n, 4, generator=g)
+pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+out = O.mlp_forward(pp, x); (out * g_out).sum().backward()
+for dtype in ("fp32", "bf16"):
+    (m,), _ = build_models([p], dev, dtype)
+    o = m(x.to(dev)); (o * g_out.to(dev)).sum().backward()
+    print(dtype, "fwd err", (o.detach().cpu() - out.detach()).abs().max().item())
+    for name, prm in m.named_parameters():
+        r = pp[name].grad; q = prm.grad.cpu()
+        print("  %-28s rel_l2 %.4f  cos %.5f  max|r| %.3e" % (name, (q - r).norm().item() / (r.norm().item() + 1e-20),
+              torch.nn.functional.cosine_similarity(q.flatten(), r.flatten(), dim=0).item(), r.abs().max().item()))
+# training loop comparison
+from nerf_pl_amd.models import render_rays
+for dtype in ("fp32", "bf16"):
+    params = [O.make_params(5, 4.0, 0.2), O.make_params(6, 4.0, 0.2)]
+    ms, emb = build_models(params, dev, dtype)
+    rays = O.make_rays(3, 256, "blender").to(dev)
+    tgt = torch.rand(256, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    opt = torch.optim.Adam([q for m in ms for q in m.parameters()], lr=5e-4)
+    torch.manual_seed(0)
+    ls = []
+    for _ in range(12):
+        res = render_rays(ms, emb, rays, 64, False, 1.0, 0.0, 64, 1024 * 32, True)
+        loss = torch.nn.functional.mse_loss(res["rgb_coarse"], tgt) + torch.nn.functional.mse_loss(res["rgb_fine"], tgt)
+        opt.zero_grad(); loss.backward(); opt.step(); ls.append(round(loss.item(), 4))
+    print(dtype, "losses", ls)
+# CPU oracle training loop with same recipe (different RNG stream, stochastic sampling) for reference
+params = [O.make_params(5, 4.0, 0.2), O.make_params(6, 4.0, 0.2)]
+for d in params:
+    for v in d.values(): v.requires_grad_(True)
+opt = torch.optim.Adam([v for d in params for v in d.values()], lr=5e-4)
+rays = O.make_rays(3, 256, "blender"); tgt = torch.rand(256, 3, generator=torch.Generator().manual_seed(0))
+ls = []
+for it in range(12):
+    rng = O.draw_rng(it, 256, 64, 64, 1.0)
+    res = O.render_rays(params, rays, 64, False, 1.0, 0.0, 64, True, False, rng=rng)
+    loss = O.mse_loss(res, tgt); opt.zero_grad(); loss.backward(); opt.step(); ls.append(round(loss.item(), 4))
+print("oracle losses", ls)
