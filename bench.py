@@ -28,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
+FLOP_PER_POINT_BWD = 2302208       # dX chain 557,696 MAC (no dX into the encodings) + dW 593,408 MAC
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
@@ -205,10 +207,37 @@ def main():
             avg_ms = sum(ms) / len(ms)
         flops = FLOP_PER_POINT_FULL * B * (S + N)
         ach = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "mlp_fwd_kernel<%s,rays,full> %dx%d points" % (a.dtype, B, S + N),
+        kname = "mlp_fwd_kernel<%s,rays,full> %dx%d points" % (a.dtype, B, S + N)
+        traffic = None      # HBM bytes per launch from the PMC passes of the same command (profiles/), else null
+        if os.path.exists(TRAFFIC_JSON):
+            with open(TRAFFIC_JSON) as fh:
+                traffic = json.load(fh).get("mlp_fwd_%s_%dx%d" % (a.dtype, B, S + N), {}).get("hbm_bytes_per_launch")
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
+                "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "min_launch_us": round(ms[0] * 1e3, 2)}
+        extra["roofline"] = roof
+        if a.mode == "train":
+            # backward of the same fine pass: fwd(save) once, then nerfhip_mlp_bwd = chain + dW + reduce kernels
+            acts = ops.alloc_acts(B * (S + N), a.dtype, dev)
+            out_f = ops.mlp_fwd_rays(rays, zf, models[1].packed_weights(), False, a.dtype, save=acts)
+            g_out = torch.randn_like(out_f)
+            pb = models[1].packed_weights_bwd()
+            for _ in range(3):
+                ops.mlp_bwd(g_out, out_f, pb, acts, a.dtype)
+            evb = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            evb[0].record()
+            for i in range(10):
+                ops.mlp_bwd(g_out, out_f, pb, acts, a.dtype)
+                evb[i + 1].record()
+            torch.cuda.synchronize()
+            bms = sum(evb[i].elapsed_time(evb[i + 1]) for i in range(10)) / 10
+            bach = FLOP_PER_POINT_BWD * B * (S + N) / (bms * 1e-3) / 1e12
+            extra["roofline_bwd"] = {"bound": "hbm+mfma", "kernel": "nerfhip_mlp_bwd<%s> = bwd_chain + bwd_dw + reduce, %dx%d points"
+                                     % (a.dtype, B, S + N), "achieved": round(bach, 2), "peak": PEAK_TFLOPS[a.dtype],
+                                     "unit": "TFLOP/s", "frac": round(bach / PEAK_TFLOPS[a.dtype], 4),
+                                     "avg_launch_us": round(bms * 1e3, 2)}
+            del acts, out_f, g_out
 
         total_rays = world * B * a.steps
         out = {
@@ -222,10 +251,9 @@ def main():
                                    "noise_std=0 white_back, %s MFMA MLP, mode=%s" % (B, S, N, a.dtype, a.mode),
                        "rays_per_gpu": B, "N_samples": S, "N_importance": N,
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if world > 1 and a.mode == "train" else "")},
-            "roofline": roof,
         }
         out.update(extra)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:                # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(B, S, N, a.cpu_seconds, a.mode == "train")
         print(json.dumps(out), flush=True)
     if dist is not None:

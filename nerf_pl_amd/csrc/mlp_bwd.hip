@@ -187,25 +187,31 @@ __device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_
     const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-        __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + 16 * q, soff, 0);
+        // soffset must stay 0 (offset folded into VOFFSET): gfx950 store-data hazard, see mlp_fwd.hip save_slabs
+        __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + soff + 16 * q, 0, 0);
         st.pending += 1;
     }
 }
 
-// acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(h) read from the saved
-// activation slabs (same register positions), store as dY section, keep as next B operand.
+// acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(pre-act), read as ONE 16-B
+// gate word per lane per layer (bit 8*ks+j, written by the forward's SAVE variant; mask_piece < 0 = no gate),
+// store as dY section, keep as next B operand.
 template <int PREC, bool MASK, int NT, typename Slab>
 __device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t acts,
-                                             int act_sec, __amdgpu_buffer_rsrc_t dys, int dy_sec, Slab* out, int lane) {
+                                             int mask_piece, __amdgpu_buffer_rsrc_t dys, int dy_sec, Slab* out, int lane) {
+    u32x4 gates = {0u, 0u, 0u, 0u};
+    if (MASK)
+        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u,
+                                                      (unsigned)(act_mask_off(PREC) + mask_piece * kPieceBytes), 0);
 #pragma unroll
     for (int ks = 0; ks < 2 * NT; ++ks) {
         float v[8];
-        Slab hsave;
-        if (MASK) hsave = load_slab<Slab>(acts, act_sec + ks, lane);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gv = acc[ks >> 1][8 * (ks & 1) + j];
-            v[j] = MASK ? (slab_get(hsave, j) > 0.0f ? gv : 0.0f) : gv;
+            const int idx = 8 * ks + j;            // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd.hip to_slabs)
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)gates[idx >> 5], 31 - (idx & 31), 1);   // 0 | ~0
+            v[j] = MASK ? __uint_as_float(__float_as_uint(gv) & m) : gv;
         }
         mk_slab(out[ks], v);
         store_slab(st, dys, dy_sec + ks, out[ks], lane);
@@ -233,8 +239,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);               // padded points contribute nothing
 
     __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(acts_base) + (size_t)tile * kActSlabs * 64 * sizeof(Slab), 0,
-        (int)(kActSlabs * 64 * sizeof(Slab)), 0x00020000);
+        const_cast<uint8_t*>(acts_base) + (size_t)tile * act_tile_bytes(PREC), 0, act_tile_bytes(PREC), 0x00020000);
     __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(
         dys_base + (size_t)tile * kDySlabs * 64 * sizeof(Slab), 0, (int)(kDySlabs * 64 * sizeof(Slab)), 0x00020000);
 
@@ -273,7 +278,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     {
         f32x16 a4[4];
         run_bwd_layer<PREC, 0, 4, 1>(st, smem_lane, &g_rgb, a4);
-        finish_layer<PREC, true>(st, a4, acts, kActT, dys, kDyDir, gd, lane);
+        finish_layer<PREC, true>(st, a4, acts, kMaskPieceT, dys, kDyDir, gd, lane);
     }
     // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)
     f32x16 acc[8];
@@ -283,10 +288,10 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     gs[16] = g_sig;
     // final^T + sigma^T : g_h8 ; mask with h8
     run_bwd_layer<PREC, 2, 8, 17>(st, smem_lane, gs, acc);
-    finish_layer<PREC, true>(st, acc, acts, act_h(8), dys, dy_h(8), gs, lane);
+    finish_layer<PREC, true>(st, acc, acts, mask_piece_h(8), dys, dy_h(8), gs, lane);
 #define NH_BWD(L)                                                                     \
     run_bwd_layer<PREC, L, 8, 16>(st, smem_lane, gs, acc);                             \
-    finish_layer<PREC, true>(st, acc, acts, act_h(10 - L), dys, dy_h(10 - L), gs, lane);
+    finish_layer<PREC, true>(st, acc, acts, mask_piece_h(10 - L), dys, dy_h(10 - L), gs, lane);
     NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
 #undef NH_BWD
 }
@@ -303,11 +308,13 @@ template <> struct DwTraits<NERFHIP_BF16> {
     static constexpr int SPP = 1;            // 1 KiB pieces per slab
     static constexpr int DEPTH = 4;          // ring stages
     static constexpr int MAXP = 36;          // max pieces per stage ((16 + 20) slabs)
+    static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
 };
 template <> struct DwTraits<NERFHIP_F32> {
     static constexpr int SPP = 2;
     static constexpr int DEPTH = 2;
     static constexpr int MAXP = 72;
+    static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
 };
 
 template <int PREC>
@@ -316,7 +323,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
                        const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
     constexpr int SPP = DwTraits<PREC>::SPP, DEPTH = DwTraits<PREC>::DEPTH, MAXP = DwTraits<PREC>::MAXP;
     constexpr int LPW = (MAXP + 7) / 8;                       // DMA instructions per wave per stage (padded)
-    constexpr int STAGE_BYTES = MAXP * kPieceBytes;
+    constexpr int STAGE_BYTES = DwTraits<PREC>::STAGE_BYTES;
     constexpr int SLAB_BYTES = SPP * kPieceBytes;
     __shared__ __attribute__((aligned(1024))) char ring[DEPTH * STAGE_BYTES];
 
@@ -331,11 +338,18 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
     const int64_t my_tiles = (ntiles - split + nsplit - 1) / nsplit;   // tiles split, split+nsplit, ...
     const unsigned lds_base = (unsigned)(uintptr_t)ring;
 
-    // stage image: [dy slabs][x1 slabs][x2 slabs], each slab SPP lane-linear pieces
+    // stage image: [dy slabs][x1 slabs][x2 slabs], each slab SPP 1 KiB pieces at 1 KiB pitch.  The DMA writes
+    // LDS lane-linearly (16-B unit L of a piece <- lane L) but each lane chooses WHICH global 16-B unit it
+    // fetches: bf16 pieces are stored in HBM as [half h][point n] and land in LDS as unit (2n+h) for even slabs
+    // and (2n+h)^8 for odd slabs, so that the 32 lanes of a ds_read_b64_tr_b16 group (4 points x 2 halves x
+    // 2 slabs x 2 j-halves) hit 32 distinct bank pairs.  (The linear [h][n] image was 4-way conflicted: the h,
+    // slab and k-step strides are all multiples of 256 B.)
+    const int dma_off_even = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + (lane >> 1)) * 16 : lane * 16;
+    const int dma_off_odd = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + ((lane ^ 8) >> 1)) * 16 : lane * 16;
     auto issue_stage = [&](int64_t it) {
         int64_t T = split + (it < my_tiles ? it : my_tiles - 1) * nsplit;   // past the end: re-fetch (keeps counts uniform)
         if (T >= ntiles) T = ntiles - 1;
-        const uint8_t* abase = acts_base + (size_t)T * kActSlabs * 64 * (16 * SPP);
+        const uint8_t* abase = acts_base + (size_t)T * act_tile_bytes(PREC);
         const uint8_t* dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);
         const unsigned slot = lds_base + (unsigned)((it % DEPTH) * STAGE_BYTES);
 #pragma unroll
@@ -349,7 +363,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
             else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
             // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
             // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
-            glds16b(src + (size_t)sub * kPieceBytes + lane * 16, slot + (unsigned)(pi * kPieceBytes));
+            glds16b(src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even), slot + (unsigned)(pi * kPieceBytes));
         }
     };
 
@@ -367,7 +381,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
     // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
     // h=b&1, j-half b>>1 of the slab image  [h][point n][8 x bf16].
     const int grp = lane >> 4, c = lane & 15;
-    const int tr_off = (grp & 1) * SLAB_BYTES + (((c & 3) & 1) * 32 + 8 * (grp >> 1) + (c >> 2)) * 16 + ((c & 3) >> 1) * 8;
+    // image unit of (point n, half h) = (2n + h) ^ (8 * slab parity);  n = 8*(grp>>1) + (c>>2) + 4*s + 16*q
+    // (s = second read of the k-step, q = k-step): bit 3 of the unit is s, so odd slabs swap the two reads.
+    const int tr_off = (grp & 1) * SLAB_BYTES + (2 * (8 * (grp >> 1) + (c >> 2)) + ((c & 3) & 1)) * 16 + ((c & 3) >> 1) * 8;
+    const int tr_s0 = (grp & 1) ? 128 : 0, tr_s1 = 128 - tr_s0;
     // fp32 gather geometry: lane (m = l&31, k = l>>5): feature m -> slab m>>4, natural i = m&15 -> (h,j)
     const int m32 = lane & 31, kk = lane >> 5;
     const int f32_off = (m32 >> 4) * SLAB_BYTES + (slab_nat_h(m32 & 15) * 32) * 32 + slab_nat_j(m32 & 15) * 4;
@@ -386,9 +403,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
                 for (int q = 0; q < 2; ++q) {                      // two 16-point k-steps per 32-point tile
                     union { s16x4 h2[2]; bf16x8 v; } a;
                     a.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 256));
+                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 512 + tr_s0));
                     a.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 256 + 64));
+                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 512 + tr_s1));
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dbacc += (float)a.v[j];
 #pragma unroll
@@ -396,9 +413,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
                         if (x < n_xt) {
                             union { s16x4 h2[2]; bf16x8 v; } b;
                             b.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 256));
+                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 512 + tr_s0));
                             b.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 256 + 64));
+                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 512 + tr_s1));
                             acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[x], 0, 0, 0);
                         }
                     }

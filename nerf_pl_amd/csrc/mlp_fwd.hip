@@ -150,8 +150,14 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, CS>& st, const
     }
 }
 
-template <bool RELU, int NT, typename Slab>
-__device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out) {
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// `gates` (SAVE variant only): value idx = 8*ks + j (slab ks, slot j) -> word idx>>5, bit 31-(idx&31) = [x > 0].
+// Pure VALU (no v_cmp: 128 live SGPR lane masks per layer spill): relu(x) is +-0 or positive, so
+// bit 31 of (bits + 0x7fffffff) is the gate; v_alignbit pushes it into the word.
+template <bool RELU, bool GATES, int NT, typename Slab>
+__device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out, u32x4* gates = nullptr) {
+    unsigned gw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -161,16 +167,37 @@ __device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out) {
             for (int j = 0; j < 8; ++j) {
                 const float x = acc[t][8 * s + j];
                 v[j] = RELU ? fmaxf(x, 0.0f) : x;
+                if (GATES) {
+                    const int idx = 8 * (2 * t + s) + j;
+                    const unsigned sb = __float_as_uint(fmaxf(x, 0.0f)) + 0x7fffffffu;
+                    gw[idx >> 5] = __builtin_amdgcn_alignbit(gw[idx >> 5], sb, 31);   // (gw << 1) | (sb >> 31)
+                }
             }
             make_slab(out[2 * t + s], v);
         }
     }
+    if (GATES) {
+        u32x4 g;
+        g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
+        *gates = g;
+    }
 }
 
 // ---- training: save B-operand slabs in register (fragment) order, one coalesced 16-B store/lane/piece ----
-// Buffer stores through a per-wave descriptor: wave-uniform section offset in an SGPR (soffset), one
-// 32-bit per-lane offset VGPR — no 64-bit address VGPR pairs competing with the accumulators.
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// Buffer stores through a per-wave descriptor with a 32-bit per-lane offset VGPR (no 64-bit address VGPR
+// pairs competing with the accumulators).  The section offset is added to the VOFFSET and soffset stays the
+// constant 0: with a wave-uniform soffset in an SGPR, LLVM's hazard recognizer assumes the ">64-bit store data
+// followed by a VALU write of the data VGPR" hazard cannot occur and lets the next VALU instruction overwrite
+// v[d:d+3] right behind the store — on gfx950 that corrupts lanes 12-15 of every 16 (measured: dY slabs with
+// 0x4000 patterns from the following v_and).  With soffset = 0 the compiler inserts the wait states.
+template <int PREC, int NCH, bool CS>
+__device__ __forceinline__ void save_gates(WeightStream<PREC, NCH, CS>& st, __amdgpu_buffer_rsrc_t rsrc, int piece,
+                                           const u32x4& g, int lane) {
+    // section offset goes into VOFFSET, soffset = 0 (gfx950 store-data hazard, see save_slabs)
+    __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (unsigned)lane * 16u + (unsigned)(act_mask_off(PREC) + piece * kPieceBytes),
+                                           0, 0);
+    st.pending += 1;
+}
 template <int PREC, int NCH, typename Slab, bool CS>
 __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __amdgpu_buffer_rsrc_t rsrc, int sec,
                                            const Slab* slabs, int n, int lane) {
@@ -181,7 +208,7 @@ __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __am
         const u32x4* src = reinterpret_cast<const u32x4*>(&slabs[i]);
 #pragma unroll
         for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + 16 * q, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + soff + 16 * q, 0, 0);
             st.pending += 1;
         }
     }
@@ -275,8 +302,8 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     st.wave = wave;
     st.pending = 0;
     __amdgpu_buffer_rsrc_t tile_base = __builtin_amdgcn_make_buffer_rsrc(
-        SAVE ? save + ((size_t)blockIdx.x * NW + wave) * kActSlabs * 64 * sizeof(Slab) : (uint8_t*)nullptr, 0,
-        SAVE ? (int)(kActSlabs * 64 * sizeof(Slab)) : 0, 0x00020000);
+        SAVE ? save + ((size_t)blockIdx.x * NW + wave) * act_tile_bytes(PREC) : (uint8_t*)nullptr, 0,
+        SAVE ? act_tile_bytes(PREC) : 0, 0x00020000);
     st.issue_chunk(0);
     if (NCH > 1) st.issue_chunk(1);
 
@@ -299,10 +326,14 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     }
     f32x16 acc[8];
     Slab hs[16];
+    u32x4 gates;
 #define NH_LAYER(L, ENC, CHAIN)                                                          \
     run_layer<PREC, L, NCH, 8>(st, smem_lane, smem_half, ENC, CHAIN, acc);                \
-    to_slabs<true>(acc, hs);                                                             \
-    if (SAVE) save_slabs(st, tile_base, act_h(L + 1), hs, 16, lane);
+    to_slabs<true, SAVE>(acc, hs, &gates);                                               \
+    if (SAVE) {                                                                          \
+        save_slabs(st, tile_base, act_h(L + 1), hs, 16, lane);                           \
+        save_gates(st, tile_base, mask_piece_h(L + 1), gates, lane);                     \
+    }
     NH_LAYER(0, encx, (const Slab*)nullptr)
     NH_LAYER(1, (const Slab*)nullptr, hs)
     NH_LAYER(2, (const Slab*)nullptr, hs)
@@ -322,13 +353,16 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         return;
     } else {
         run_layer<PREC, 9, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-        to_slabs<false>(acc, hs);                            // xyz_encoding_final: no activation
+        to_slabs<false, false>(acc, hs);                     // xyz_encoding_final: no activation
         if (SAVE) save_slabs(st, tile_base, kActFeat, hs, 16, lane);
         f32x16 dacc[4];
         run_layer<PREC, 10, NCH, 4>(st, smem_lane, smem_half, encd, hs, dacc);
         Slab hd[8];
-        to_slabs<true>(dacc, hd);
-        if (SAVE) save_slabs(st, tile_base, kActT, hd, 8, lane);
+        to_slabs<true, SAVE>(dacc, hd, &gates);
+        if (SAVE) {
+            save_slabs(st, tile_base, kActT, hd, 8, lane);
+            save_gates(st, tile_base, kMaskPieceT, gates, lane);
+        }
         f32x16 racc[1];
         run_layer<PREC, 11, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hd, racc);
         if (valid && h == 0) {
@@ -368,7 +402,7 @@ extern "C" size_t nerfhip_mlp_act_bytes(int64_t n_points, int dtype) {
     if (n_points < 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
     const int64_t ppw = 32 * (dtype == NERFHIP_BF16 ? 8 : 4);                 // points per workgroup
     const int64_t tiles = (n_points + ppw - 1) / ppw * (ppw / 32);             // whole workgroups are written
-    return (size_t)tiles * nerfhip::mlp::kActSlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
+    return (size_t)tiles * nerfhip::mlp::act_tile_bytes(dtype);
 }
 
 extern "C" int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const void* packed, float* out,

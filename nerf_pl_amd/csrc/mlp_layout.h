@@ -132,6 +132,15 @@ NH_HD constexpr int act_h(int l) { return kActH0 + 16 * (l - 1); }   // l = 1..8
 constexpr int kActFeat = kActH0 + 128;      // 16 slabs  xyz_encoding_final output (no activation)
 constexpr int kActT = kActFeat + 16;        // 8 slabs   dir_encoding output (post-ReLU)
 constexpr int kActSlabs = kActT + 8;        // 158
+// ReLU gates: after the slabs of a tile, one 1 KiB piece per gated layer (h1..h8, t): lane's 16 B hold, for value
+// idx = 8*ks + j (slab ks, slot j), [pre-activation > 0] at word idx>>5, bit 31-(idx&31).  The backward chain reads these 9 KiB per tile instead of
+// the 136 KiB of activation slabs.
+constexpr int kMaskPieces = 9;
+NH_HD constexpr int mask_piece_h(int l) { return l - 1; }            // l = 1..8
+constexpr int kMaskPieceT = 8;
+NH_HD constexpr int slab_bytes(int prec) { return prec == 0 /*NERFHIP_F32*/ ? 32 * 64 : 16 * 64; }
+NH_HD constexpr int act_mask_off(int prec) { return kActSlabs * slab_bytes(prec); }
+NH_HD constexpr int act_tile_bytes(int prec) { return act_mask_off(prec) + kMaskPieces * kPieceBytes; }
 
 // Backward chain writes dL/d(pre-activation) slabs in the same format.
 constexpr int kDyRgb = 0;                   // 2 slabs (3 real features, rest zero)
