@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnerfhip.so")
+LIB_PATH = os.environ.get("NERFHIP_LIB_PATH") or os.path.join(_PKG, "libnerfhip.so")   # override: A/B kernel builds
 
 F32, BF16 = 0, 1
 

@@ -11,8 +11,14 @@
 // s_barrier per 32 KiB chunk and two chunks always in flight (counted vmcnt, never drained to 0).
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, 8 waves (2 per SIMD) = 256 points / workgroup
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), 4 waves (1 per SIMD) = 128 points / workgroup
+#include <type_traits>
+
 #include "common.h"
 #include "mlp_layout.h"
+
+#ifndef NERFHIP_PF2
+#define NERFHIP_PF2 2      // prefetch depth of the 2-waves-per-SIMD (256-register) bf16 kernels
+#endif
 
 namespace nerfhip {
 using namespace mlp;
@@ -21,17 +27,26 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int PREC> struct PrecTraits;
 template <> struct PrecTraits<NERFHIP_BF16> {
     using Slab = bf16x8;                 // 8 input features of one point (4 VGPRs)
-    static constexpr int NW = 8;         // waves per workgroup
-    static constexpr int WPS = 2;        // waves per SIMD (launch bound)
 };
 template <> struct PrecTraits<NERFHIP_F32> {
     using Slab = f32x8;                  // 8 VGPRs
-    static constexpr int NW = 4;
-    static constexpr int WPS = 1;
+};
+
+// Launch geometry.  Inference bf16: 8 waves (2 per SIMD, 256 regs each) = 256 points / workgroup, the two waves of
+// a SIMD overlap each other's epilogue VALU with MFMA.  Training (SAVE) bf16: 4 waves (1 per SIMD, 512 regs):
+// acc (128) + B slabs (64) + the slabs queued for the activation stores do not fit 256 registers (189 spilled
+// VGPRs = +15 % HBM writes through scratch), and that variant is HBM-write-bound anyway.  fp32: 4 waves.
+template <int PREC, bool SAVE> struct KCfg {
+    static constexpr int NW = (PREC == NERFHIP_BF16 && !SAVE) ? 8 : 4;
+    static constexpr int WPS = (PREC == NERFHIP_BF16 && !SAVE) ? 2 : 1;
+    // A-fragment software prefetch depth (bf16): LDS reads issued this many MFMAs ahead of their use, so the
+    // ~100-cycle ds_read latency is not exposed once per 32-cycle MFMA
+    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : (SAVE ? 8 : NERFHIP_PF2);
 };
 
 __device__ __forceinline__ void make_slab(bf16x8& s, const float (&v)[8]) {
@@ -55,7 +70,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 
 template <int PREC, int NCH, bool COUNT_STORES = false>
 struct WeightStream {
-    static constexpr int NW = PrecTraits<PREC>::NW;
+    static constexpr int NW = KCfg<PREC, COUNT_STORES>::NW;    // COUNT_STORES == SAVE variant
     static constexpr int LPW = kChunkPieces / NW;   // DMA instructions per wave per chunk
     const uint8_t* gsrc;     // packed + lane*16
     unsigned lds_base;       // LDS byte address of the ring
@@ -63,13 +78,22 @@ struct WeightStream {
     int pending;             // vector-memory STORE instructions issued since the last boundary (SAVE variant).
                              // Straight-line code: the optimiser folds this to a constant at every boundary.
 
+    __device__ __forceinline__ void issue_piece(int c, int k) const {      // k-th of this wave's LPW pieces of chunk c
+        const int piece = wave + k * NW;
+        glds16(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
+               lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
+    }
     __device__ __forceinline__ void issue_chunk(int c) const {
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int piece = wave + i * NW;
-            glds16(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
-                   lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
-        }
+        for (int i = 0; i < LPW; ++i) issue_piece(c, i);
+    }
+    // Called once for EVERY piece index G of the stream, in increasing order, right before piece G is read: the
+    // first piece of a chunk is the chunk boundary.  (Measured: spreading the LPW refill DMAs over the chunk and
+    // staggering them between the two halves of the workgroup — instead of one burst behind the barrier — is
+    // SLOWER: 203 vs 184 us forward, and 3x on the 4-wave SAVE variant; the burst stays.)
+    template <int G>
+    __device__ __forceinline__ void at_piece() {
+        if constexpr (G % kChunkPieces == 0) boundary(G / kChunkPieces);
     }
     // Called by every wave right before the first piece of chunk c is read.
     __device__ __forceinline__ void boundary(int c) {
@@ -102,84 +126,12 @@ struct WeightStream {
     }
 };
 
-// ---- one layer: acc[t] = bias + sum over slabs W_frag(ks,t) * B[ks] -----------------------------
-template <int PREC, int L, int NCH, int NT, typename Slab, bool CS>
-__device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, CS>& st, const char* smem_lane,
-                                          const char* smem_half, const Slab* enc, const Slab* chain,
-                                          f32x16 (&acc)[NT]) {
-    constexpr Layer ly = kLayers[L];
-    static_assert(ly.nt == NT, "tile count mismatch");
-    constexpr int G0 = layer_start(L, PREC);
-    constexpr int PPF = ppf(PREC);
-    constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
-
-    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
-
-    // bias piece -> accumulator init.  Row of reg r: 32t + (r&3) + 8(r>>2) + 4h  => one f32x4 per (t, r>>2).
-    if (G0 % kChunkPieces == 0) st.boundary(G0 / kChunkPieces);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(smem_half + piece_off(G0) + (32 * t + 8 * q) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][4 * q + i] = b[i];
-        }
-    }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const Slab bs = (ks < ly.enc_slabs) ? enc[ks < ly.enc_slabs ? ks : 0]
-                                            : chain[ks >= ly.enc_slabs ? ks - ly.enc_slabs : 0];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int g = G0 + 1 + (ks * NT + t) * PPF;
-            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
-            if constexpr (PREC == NERFHIP_BF16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs, acc[t], 0, 0, 0);
-            } else {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
-                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bs[j], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-// `gates` (SAVE variant only): value idx = 8*ks + j (slab ks, slot j) -> word idx>>5, bit 31-(idx&31) = [x > 0].
-// Pure VALU (no v_cmp: 128 live SGPR lane masks per layer spill): relu(x) is +-0 or positive, so
-// bit 31 of (bits + 0x7fffffff) is the gate; v_alignbit pushes it into the word.
-template <bool RELU, bool GATES, int NT, typename Slab>
-__device__ __forceinline__ void to_slabs(const f32x16 (&acc)[NT], Slab* out, u32x4* gates = nullptr) {
-    unsigned gw[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = acc[t][8 * s + j];
-                v[j] = RELU ? fmaxf(x, 0.0f) : x;
-                if (GATES) {
-                    const int idx = 8 * (2 * t + s) + j;
-                    const unsigned sb = __float_as_uint(fmaxf(x, 0.0f)) + 0x7fffffffu;
-                    gw[idx >> 5] = __builtin_amdgcn_alignbit(gw[idx >> 5], sb, 31);   // (gw << 1) | (sb >> 31)
-                }
-            }
-            make_slab(out[2 * t + s], v);
-        }
-    }
-    if (GATES) {
-        u32x4 g;
-        g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
-        *gates = g;
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — guarantees static register indexing
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
     }
 }
 
@@ -211,6 +163,111 @@ __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __am
             __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + soff + 16 * q, 0, 0);
             st.pending += 1;
         }
+    }
+}
+
+// ---- one layer, OUTPUT-TILE-MAJOR: for each 32-row output tile t: acc = bias; acc += W_frag(t,ks) * B[ks] over all
+// input slabs ks; then that tile's epilogue (activation, pack to the next layer's B slabs 2t and 2t+1, ReLU gate
+// bits, activation stores) runs while the matrix pipe already works on tile t+1 (other accumulator).  The
+// epilogue VALU is thereby spread over the layer in 1/NT portions instead of one block at the layer end, where —
+// all waves being chunk-synchronised by the weight ring's barriers — it used to stall every SIMD's MFMA pipe at once.
+// Weights are packed in the same (t, ks) order (mlp_pack.hip); fragment i = t*NKS + ks = piece G0 + 1 + i*PPF.
+//   out != nullptr : `out[2t], out[2t+1]` receive the activated slabs;   heads (NT == 1) return the raw tile in *raw.
+template <int PREC, int L, int NCH, int NT, bool RELU, bool SAVE, typename Slab>
+__device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, SAVE>& st, const char* smem_lane, char* bias_priv,
+                                          const Slab* enc, const Slab* chain, Slab* out, f32x16* raw,
+                                          __amdgpu_buffer_rsrc_t rsrc, int act_sec, int gate_piece, int lane) {
+    constexpr Layer ly = kLayers[L];
+    static_assert(ly.nt == NT, "tile count mismatch");
+    constexpr int G0 = layer_start(L, PREC);
+    constexpr int PPF = ppf(PREC);
+    constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
+    constexpr int N = NT * NKS;
+    constexpr int D = (KCfg<PREC, SAVE>::PF < N) ? KCfg<PREC, SAVE>::PF : N;    // A-fragment prefetch depth
+
+    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
+    // A fragment i: bf16 = one 16-B read per lane; fp32 = two (8 x f32)
+    auto load_frag = [&](auto ic, Slab& a) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int g = G0 + 1 + i * PPF;
+        st.template at_piece<g>();
+        if constexpr (PREC == NERFHIP_BF16) {
+            a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
+        } else {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
+            st.template at_piece<g + 1>();
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = a0[j]; a[4 + j] = a1[j]; }
+        }
+    };
+
+    st.template at_piece<G0>();
+    // The layer's bias piece is needed at the start of EVERY output tile, by which time its ring slot may have been
+    // refilled (a layer spans up to 5 chunks): copy it once into this wave's private 1 KiB of LDS (same-wave LDS
+    // operations execute in order, so no barrier is needed).
+    {
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(smem_lane + piece_off(G0));
+        *reinterpret_cast<u32x4*>(bias_priv + lane * 16) = bv;
+    }
+    Slab a[D];
+    static_for<0, D>([&](auto ic) { load_frag(ic, a[decltype(ic)::value]); });
+
+    f32x16 acc[2];
+    unsigned gw[4] = {0u, 0u, 0u, 0u};
+    static_for<0, N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = i / NKS, ks = i % NKS;
+        f32x16& c = acc[t & 1];
+        if constexpr (ks == 0) {
+            // bias -> accumulator init.  Row of reg r: 32t + (r&3) + 8(r>>2) + 4h  => one f32x4 per (t, r>>2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias_priv + (lane >> 5) * 16 + (32 * t + 8 * q) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[4 * q + k] = b[k];
+            }
+        }
+        const Slab bs = (ks < ly.enc_slabs) ? enc[ks < ly.enc_slabs ? ks : 0]
+                                            : chain[ks >= ly.enc_slabs ? ks - ly.enc_slabs : 0];
+        if constexpr (PREC == NERFHIP_BF16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % D], bs, c, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i % D][j], bs[j], c, 0, 0, 0);
+        }
+        if constexpr (i + D < N) load_frag(std::integral_constant<int, i + D>{}, a[i % D]);
+
+        if constexpr (ks == NKS - 1) {                       // ---- epilogue of tile t ----
+            if constexpr (NT == 1) {                         // heads: hand the raw tile back
+                *raw = c;
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = c[8 * sl + j];
+                        v[j] = RELU ? fmaxf(x, 0.0f) : x;
+                        if (RELU && SAVE) {
+                            // ReLU gate of value idx = 8*(2t+sl) + j -> word idx>>5, bit 31-(idx&31).  Pure VALU (no
+                            // v_cmp: 128 live SGPR lane masks per layer spill): relu(x) is +-0 or positive, so bit 31 of
+                            // (bits + 0x7fffffff) is [x > 0]; v_alignbit pushes it into the word.
+                            const int idx = 8 * (2 * t + sl) + j;
+                            const unsigned sb = __float_as_uint(v[j]) + 0x7fffffffu;
+                            gw[idx >> 5] = __builtin_amdgcn_alignbit(gw[idx >> 5], sb, 31);   // (gw << 1) | (sb >> 31)
+                        }
+                    }
+                    make_slab(out[2 * t + sl], v);
+                }
+                if (SAVE) save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
+            }
+        }
+    });
+    if constexpr (SAVE && RELU && NT != 1) {
+        u32x4 g;
+        g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
+        save_gates(st, rsrc, gate_piece, g, lane);
     }
 }
 
@@ -264,13 +321,13 @@ __device__ __forceinline__ void load_slots(const float* __restrict__ row, int h,
 constexpr int MODE_EMBEDDED = 0, MODE_RAYS = 1;
 
 template <int PREC, int MODE, bool SIGMA_ONLY, bool SAVE>
-__global__ __launch_bounds__(PrecTraits<PREC>::NW * 64, PrecTraits<PREC>::WPS)
+__global__ __launch_bounds__((KCfg<PREC, SAVE>::NW * 64), (KCfg<PREC, SAVE>::WPS))
 void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
                     const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save) {
     using Slab = typename PrecTraits<PREC>::Slab;
-    constexpr int NW = PrecTraits<PREC>::NW;
+    constexpr int NW = KCfg<PREC, SAVE>::NW;
     constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
-    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
+    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * kPieceBytes];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -308,7 +365,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     if (NCH > 1) st.issue_chunk(1);
 
     const char* smem_lane = ring + lane * 16;
-    const char* smem_half = ring + h * 16;
+    char* smem_half = ring + kSlots * kChunkBytes + wave * kPieceBytes;    // this wave's private bias copy (run_layer)
 
     Slab encx[kXyzSlabs];
     Slab encd[kDirSlabs];
@@ -324,52 +381,43 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
         save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
     }
-    f32x16 acc[8];
-    Slab hs[16];
-    u32x4 gates;
-#define NH_LAYER(L, ENC, CHAIN)                                                          \
-    run_layer<PREC, L, NCH, 8>(st, smem_lane, smem_half, ENC, CHAIN, acc);                \
-    to_slabs<true, SAVE>(acc, hs, &gates);                                               \
-    if (SAVE) {                                                                          \
-        save_slabs(st, tile_base, act_h(L + 1), hs, 16, lane);                           \
-        save_gates(st, tile_base, mask_piece_h(L + 1), gates, lane);                     \
-    }
-    NH_LAYER(0, encx, (const Slab*)nullptr)
-    NH_LAYER(1, (const Slab*)nullptr, hs)
-    NH_LAYER(2, (const Slab*)nullptr, hs)
-    NH_LAYER(3, (const Slab*)nullptr, hs)
-    NH_LAYER(4, encx, hs)
-    NH_LAYER(5, (const Slab*)nullptr, hs)
-    NH_LAYER(6, (const Slab*)nullptr, hs)
-    NH_LAYER(7, (const Slab*)nullptr, hs)
+    // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
+    Slab ha[16], hb[16];
+    f32x16 raw;
+#define NH_LAYER(L, ENC, IN, OUT)                                                                          \
+    run_layer<PREC, L, NCH, 8, true, SAVE>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
+                                           act_h(L + 1), mask_piece_h(L + 1), lane);
+    NH_LAYER(0, encx, (const Slab*)nullptr, ha)
+    NH_LAYER(1, (const Slab*)nullptr, ha, hb)
+    NH_LAYER(2, (const Slab*)nullptr, hb, ha)
+    NH_LAYER(3, (const Slab*)nullptr, ha, hb)
+    NH_LAYER(4, encx, hb, ha)
+    NH_LAYER(5, (const Slab*)nullptr, ha, hb)
+    NH_LAYER(6, (const Slab*)nullptr, hb, ha)
+    NH_LAYER(7, (const Slab*)nullptr, ha, hb)              // h8 -> hb
 #undef NH_LAYER
 
-    f32x16 sacc[1];
-    run_layer<PREC, 8, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, sacc);
-    const float sigma = sacc[0][0];                         // row 0 lives in reg 0 of the h=0 lanes
+    run_layer<PREC, 8, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, (Slab*)nullptr, &raw,
+                                            tile_base, 0, 0, lane);
+    const float sigma = raw[0];                              // row 0 lives in reg 0 of the h=0 lanes
 
     if (SIGMA_ONLY) {
         if (valid && h == 0) out[p] = sigma;                // (n,1)   nerf.py:112-114
         return;
     } else {
-        run_layer<PREC, 9, NCH, 8>(st, smem_lane, smem_half, (const Slab*)nullptr, hs, acc);
-        to_slabs<false, false>(acc, hs);                     // xyz_encoding_final: no activation
-        if (SAVE) save_slabs(st, tile_base, kActFeat, hs, 16, lane);
-        f32x16 dacc[4];
-        run_layer<PREC, 10, NCH, 4>(st, smem_lane, smem_half, encd, hs, dacc);
-        Slab hd[8];
-        to_slabs<true, SAVE>(dacc, hd, &gates);
-        if (SAVE) {
-            save_slabs(st, tile_base, kActT, hd, 8, lane);
-            save_gates(st, tile_base, kMaskPieceT, gates, lane);
-        }
-        f32x16 racc[1];
-        run_layer<PREC, 11, NCH, 1>(st, smem_lane, smem_half, (const Slab*)nullptr, hd, racc);
+        // xyz_encoding_final: no activation (nerf.py:116) -> ha
+        run_layer<PREC, 9, NCH, 8, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, ha, (f32x16*)nullptr,
+                                                tile_base, kActFeat, 0, lane);
+        // dir_encoding: relu(W [feat | dir])  (nerf.py:118-119) -> hb[0..7]
+        run_layer<PREC, 10, NCH, 4, true, SAVE>(st, smem_lane, smem_half, encd, ha, hb, (f32x16*)nullptr, tile_base, kActT,
+                                                kMaskPieceT, lane);
+        run_layer<PREC, 11, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, (Slab*)nullptr, &raw,
+                                                 tile_base, 0, 0, lane);
         if (valid && h == 0) {
             float4 o;
-            o.x = 1.0f / (1.0f + expf(-racc[0][0]));        // sigmoid   nerf.py:79-81
-            o.y = 1.0f / (1.0f + expf(-racc[0][1]));
-            o.z = 1.0f / (1.0f + expf(-racc[0][2]));
+            o.x = 1.0f / (1.0f + expf(-raw[0]));            // sigmoid   nerf.py:79-81
+            o.y = 1.0f / (1.0f + expf(-raw[1]));
+            o.z = 1.0f / (1.0f + expf(-raw[2]));
             o.w = sigma;                                     // cat([rgb, sigma])   nerf.py:122
             reinterpret_cast<float4*>(out)[p] = o;
         }
@@ -379,14 +427,18 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 template <int PREC, int MODE>
 static int launch_fwd(const float* in0, const float* in1, int64_t n, int64_t aux, const void* packed, float* out,
                       int sigma_only, void* save, hipStream_t stream) {
-    constexpr int NW = PrecTraits<PREC>::NW;
+    constexpr int NW = KCfg<PREC, false>::NW;
     const int64_t blocks = (n + 32 * NW - 1) / (32 * NW);
     if (blocks > 0x7fffffff) return NERFHIP_E_BADARG;
     dim3 grid((unsigned)blocks), block(NW * 64);
     if (save) {
         if (sigma_only) return NERFHIP_E_UNSUPPORTED;
-        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false, true>), grid, block, 0, stream, in0, in1, n, aux,
-                           (const uint8_t*)packed, out, (uint8_t*)save);
+        // every tile of the (workgroup-padded) activation block must be written: the backward reads them all
+        constexpr int NWS = KCfg<PREC, true>::NW;
+        const int64_t ppw = 32 * (PREC == NERFHIP_BF16 ? 8 : 4);                  // padding unit of nerfhip_mlp_act_bytes
+        const int64_t tiles = (n + ppw - 1) / ppw * (ppw / 32);
+        hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, false, true>), dim3((unsigned)(tiles / NWS)), dim3(NWS * 64), 0, stream,
+                           in0, in1, n, aux, (const uint8_t*)packed, out, (uint8_t*)save);
     } else if (sigma_only)
         hipLaunchKernelGGL((mlp_fwd_kernel<PREC, MODE, true, false>), grid, block, 0, stream, in0, in1, n, aux,
                            (const uint8_t*)packed, out, (uint8_t*)nullptr);

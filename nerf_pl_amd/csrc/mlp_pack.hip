@@ -35,7 +35,8 @@ __global__ __launch_bounds__(64) void mlp_pack_kernel(ParamTable P, uint8_t* __r
             outv = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
         } else {
             const int f = (rel - 1) / ppf(PREC), sub = (rel - 1) % ppf(PREC);
-            const int ks = f / ly.nt, t = f % ly.nt;
+            const int nks = ly.enc_slabs + ly.chain_slabs;
+            const int t = f / nks, ks = f % nks;                   // output-tile-major (mlp_fwd.hip run_layer)
             const int row = 32 * t + m;
             const float* W = P.w[ly.param];
             const int ldw = kParamIn[ly.param];
