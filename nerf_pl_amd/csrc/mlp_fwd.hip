@@ -16,6 +16,9 @@
 #include "common.h"
 #include "mlp_layout.h"
 
+#ifndef NERFHIP_TILE_SCHED_BARRIER
+#define NERFHIP_TILE_SCHED_BARRIER 0
+#endif
 #ifndef NERFHIP_PF2
 #define NERFHIP_PF2 2      // prefetch depth of the 2-waves-per-SIMD (256-register) bf16 kernels
 #endif
@@ -37,16 +40,18 @@ template <> struct PrecTraits<NERFHIP_F32> {
     using Slab = f32x8;                  // 8 VGPRs
 };
 
-// Launch geometry.  Inference bf16: 8 waves (2 per SIMD, 256 regs each) = 256 points / workgroup, the two waves of
-// a SIMD overlap each other's epilogue VALU with MFMA.  Training (SAVE) bf16: 4 waves (1 per SIMD, 512 regs):
-// acc (128) + B slabs (64) + the slabs queued for the activation stores do not fit 256 registers (189 spilled
-// VGPRs = +15 % HBM writes through scratch), and that variant is HBM-write-bound anyway.  fp32: 4 waves.
+// Launch geometry.  bf16: 8 waves (2 per SIMD, 256 regs each) = 256 points / workgroup, the two waves of a SIMD
+// overlap each other's epilogue VALU / activation stores with MFMA.  fp32: 4 waves (1 per SIMD, 512 regs; an fp32
+// slab set is 128 registers).  NERFHIP_SAVE8=0 builds the bf16 training (SAVE) variant with 4 waves as well.
 template <int PREC, bool SAVE> struct KCfg {
-    static constexpr int NW = (PREC == NERFHIP_BF16 && !SAVE) ? 8 : 4;
-    static constexpr int WPS = (PREC == NERFHIP_BF16 && !SAVE) ? 2 : 1;
+#ifndef NERFHIP_SAVE8
+#define NERFHIP_SAVE8 1    // measured: the 4-wave/512-register SAVE build is bimodal across MI355X boxes (376 us on some,
+#endif                     // ~900 us on others, same binary); the 8-wave build is 460-520 us everywhere
+    static constexpr int NW = (PREC == NERFHIP_BF16 && (!SAVE || NERFHIP_SAVE8)) ? 8 : 4;
+    static constexpr int WPS = (PREC == NERFHIP_BF16 && (!SAVE || NERFHIP_SAVE8)) ? 2 : 1;
     // A-fragment software prefetch depth (bf16): LDS reads issued this many MFMAs ahead of their use, so the
     // ~100-cycle ds_read latency is not exposed once per 32-cycle MFMA
-    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : (SAVE ? 8 : NERFHIP_PF2);
+    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : ((SAVE && !NERFHIP_SAVE8) ? 8 : NERFHIP_PF2);
 };
 
 __device__ __forceinline__ void make_slab(bf16x8& s, const float (&v)[8]) {
@@ -143,24 +148,30 @@ __device__ __forceinline__ void static_for(F&& f) {
 // v[d:d+3] right behind the store — on gfx950 that corrupts lanes 12-15 of every 16 (measured: dY slabs with
 // 0x4000 patterns from the following v_and).  With soffset = 0 the compiler inserts the wait states.
 template <int PREC, int NCH, bool CS>
-__device__ __forceinline__ void save_gates(WeightStream<PREC, NCH, CS>& st, __amdgpu_buffer_rsrc_t rsrc, int piece,
+__device__ __forceinline__ void save_gates(WeightStream<PREC, NCH, CS>& st, uint8_t* tile_ptr, int piece,
                                            const u32x4& g, int lane) {
-    // section offset goes into VOFFSET, soffset = 0 (gfx950 store-data hazard, see save_slabs)
-    __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (unsigned)lane * 16u + (unsigned)(act_mask_off(PREC) + piece * kPieceBytes),
-                                           0, 0);
+    // section offset goes into the descriptor BASE (SALU), soffset = 0 (gfx950 store-data hazard, see save_slabs)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + act_mask_off(PREC) + piece * kPieceBytes, 0,
+                                                                  kPieceBytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, (unsigned)lane * 16u, 0, 0);
     st.pending += 1;
 }
 template <int PREC, int NCH, typename Slab, bool CS>
-__device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __amdgpu_buffer_rsrc_t rsrc, int sec,
+__device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, uint8_t* tile_ptr, int sec,
                                            const Slab* slabs, int n, int lane) {
+    // One descriptor per call with the section offset folded into its (wave-uniform, SALU-computed) base: every store
+    // then uses the SAME voffset VGPR (lane * sizeof(Slab)) and a small immediate.  (Folding the section offset into
+    // the voffset instead made hipcc hoist ~40 distinct per-lane offset VGPRs to the top of the kernel: +80 live
+    // registers, spills.)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + (size_t)sec * 64 * sizeof(Slab), 0,
+                                                                  (int)(n * 64 * sizeof(Slab)), 0x00020000);
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-        const unsigned soff = (unsigned)((sec + i) * 64 * sizeof(Slab));
         const u32x4* src = reinterpret_cast<const u32x4*>(&slabs[i]);
 #pragma unroll
         for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + soff + 16 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(src[q], rs, voff + (unsigned)(i * 64 * sizeof(Slab)) + 16 * q, 0, 0);
             st.pending += 1;
         }
     }
@@ -175,8 +186,8 @@ __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, __am
 //   out != nullptr : `out[2t], out[2t+1]` receive the activated slabs;   heads (NT == 1) return the raw tile in *raw.
 template <int PREC, int L, int NCH, int NT, bool RELU, bool SAVE, typename Slab>
 __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, SAVE>& st, const char* smem_lane, char* bias_priv,
-                                          const Slab* enc, const Slab* chain, Slab* out, f32x16* raw,
-                                          __amdgpu_buffer_rsrc_t rsrc, int act_sec, int gate_piece, int lane) {
+                                          const char* enc_lds, const Slab* chain, Slab* out, f32x16* raw,
+                                          uint8_t* rsrc, int act_sec, int gate_piece, int lane) {
     constexpr Layer ly = kLayers[L];
     static_assert(ly.nt == NT, "tile count mismatch");
     constexpr int G0 = layer_start(L, PREC);
@@ -228,8 +239,11 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, SAVE>& st, con
                 for (int k = 0; k < 4; ++k) c[4 * q + k] = b[k];
             }
         }
-        const Slab bs = (ks < ly.enc_slabs) ? enc[ks < ly.enc_slabs ? ks : 0]
-                                            : chain[ks >= ly.enc_slabs ? ks - ly.enc_slabs : 0];
+        // B operand: an input-encoding slab (parked in this wave's LDS stash, enc_lds = base + lane*sizeof(Slab))
+        // or a slab of the previous layer's activations (registers)
+        Slab bs;
+        if constexpr (ks < ly.enc_slabs) bs = *reinterpret_cast<const Slab*>(enc_lds + ks * 64 * (int)sizeof(Slab));
+        else bs = chain[ks - ly.enc_slabs];
         if constexpr (PREC == NERFHIP_BF16) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % D], bs, c, 0, 0, 0);
         } else {
@@ -262,6 +276,9 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, SAVE>& st, con
                 }
                 if (SAVE) save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
             }
+#if NERFHIP_TILE_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from stretching live ranges across tiles
+#endif
         }
     });
     if constexpr (SAVE && RELU && NT != 1) {
@@ -327,7 +344,10 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     using Slab = typename PrecTraits<PREC>::Slab;
     constexpr int NW = KCfg<PREC, SAVE>::NW;
     constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
-    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * kPieceBytes];
+    // LDS: weight ring | per-wave bias copy (1 KiB) | per-wave input-encoding stash (6 slabs: the encodings are
+    // needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) / 48 (fp32) registers)
+    constexpr int kEncStash = (kXyzSlabs + kDirSlabs) * 64 * (int)sizeof(Slab);
+    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * kPieceBytes + NW * kEncStash];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -358,9 +378,8 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     st.lds_base = (unsigned)(uintptr_t)ring;
     st.wave = wave;
     st.pending = 0;
-    __amdgpu_buffer_rsrc_t tile_base = __builtin_amdgcn_make_buffer_rsrc(
-        SAVE ? save + ((size_t)blockIdx.x * NW + wave) * act_tile_bytes(PREC) : (uint8_t*)nullptr, 0,
-        SAVE ? act_tile_bytes(PREC) : 0, 0x00020000);
+    // wave-uniform base of this wave's activation block (SAVE); the store helpers derive descriptors from it
+    uint8_t* tile_base = SAVE ? save + ((size_t)blockIdx.x * NW + wave) * act_tile_bytes(PREC) : (uint8_t*)nullptr;
     st.issue_chunk(0);
     if (NCH > 1) st.issue_chunk(1);
 
@@ -381,23 +400,31 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
         save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
     }
+    char* enc_x = ring + kSlots * kChunkBytes + NW * kPieceBytes + wave * kEncStash + lane * (int)sizeof(Slab);
+    char* enc_d = enc_x + kXyzSlabs * 64 * (int)sizeof(Slab);
+#pragma unroll
+    for (int k = 0; k < kXyzSlabs; ++k) *reinterpret_cast<Slab*>(enc_x + k * 64 * (int)sizeof(Slab)) = encx[k];
+    if (!SIGMA_ONLY) {
+#pragma unroll
+        for (int k = 0; k < kDirSlabs; ++k) *reinterpret_cast<Slab*>(enc_d + k * 64 * (int)sizeof(Slab)) = encd[k];
+    }
     // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
     Slab ha[16], hb[16];
     f32x16 raw;
 #define NH_LAYER(L, ENC, IN, OUT)                                                                          \
     run_layer<PREC, L, NCH, 8, true, SAVE>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
                                            act_h(L + 1), mask_piece_h(L + 1), lane);
-    NH_LAYER(0, encx, (const Slab*)nullptr, ha)
-    NH_LAYER(1, (const Slab*)nullptr, ha, hb)
-    NH_LAYER(2, (const Slab*)nullptr, hb, ha)
-    NH_LAYER(3, (const Slab*)nullptr, ha, hb)
-    NH_LAYER(4, encx, hb, ha)
-    NH_LAYER(5, (const Slab*)nullptr, ha, hb)
-    NH_LAYER(6, (const Slab*)nullptr, hb, ha)
-    NH_LAYER(7, (const Slab*)nullptr, ha, hb)              // h8 -> hb
+    NH_LAYER(0, enc_x, (const Slab*)nullptr, ha)
+    NH_LAYER(1, (const char*)nullptr, ha, hb)
+    NH_LAYER(2, (const char*)nullptr, hb, ha)
+    NH_LAYER(3, (const char*)nullptr, ha, hb)
+    NH_LAYER(4, enc_x, hb, ha)
+    NH_LAYER(5, (const char*)nullptr, ha, hb)
+    NH_LAYER(6, (const char*)nullptr, hb, ha)
+    NH_LAYER(7, (const char*)nullptr, ha, hb)              // h8 -> hb
 #undef NH_LAYER
 
-    run_layer<PREC, 8, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, (Slab*)nullptr, &raw,
+    run_layer<PREC, 8, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
                                             tile_base, 0, 0, lane);
     const float sigma = raw[0];                              // row 0 lives in reg 0 of the h=0 lanes
 
@@ -406,12 +433,12 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         return;
     } else {
         // xyz_encoding_final: no activation (nerf.py:116) -> ha
-        run_layer<PREC, 9, NCH, 8, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, ha, (f32x16*)nullptr,
+        run_layer<PREC, 9, NCH, 8, false, SAVE>(st, smem_lane, smem_half, (const char*)nullptr, hb, ha, (f32x16*)nullptr,
                                                 tile_base, kActFeat, 0, lane);
         // dir_encoding: relu(W [feat | dir])  (nerf.py:118-119) -> hb[0..7]
-        run_layer<PREC, 10, NCH, 4, true, SAVE>(st, smem_lane, smem_half, encd, ha, hb, (f32x16*)nullptr, tile_base, kActT,
+        run_layer<PREC, 10, NCH, 4, true, SAVE>(st, smem_lane, smem_half, enc_d, ha, hb, (f32x16*)nullptr, tile_base, kActT,
                                                 kMaskPieceT, lane);
-        run_layer<PREC, 11, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const Slab*)nullptr, hb, (Slab*)nullptr, &raw,
+        run_layer<PREC, 11, NCH, 1, false, SAVE>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
                                                  tile_base, 0, 0, lane);
         if (valid && h == 0) {
             float4 o;

@@ -76,7 +76,7 @@ class GraphRenderer:
 
     def _pack(self):
         for m in self.models:
-            m.packed_weights()          # refreshes in place (same device buffer) when parameters changed
+            m.packed_weights()          # repack into the same device buffers the captured graph reads
 
     def _capture(self):
         self._pack()

@@ -79,30 +79,29 @@ class NeRF(nn.Module):
         return [l.weight for l in ls] + [l.bias for l in ls]
 
     def packed_weights(self, dtype=None):
-        """MFMA-fragment-ordered copy of the parameters, rebuilt only when a parameter changed."""
+        """MFMA-fragment-ordered image of the CURRENT parameters (one ~6 us HIP launch into a reused buffer).
+
+        Repacked on every call: parameter version counters are not a safe cache key — fused/foreach optimizers
+        (`torch.optim.Adam(fused=True)`) update parameters without bumping `_version`, and a stale image would
+        silently render/train with old weights.  Callers that know the weights are frozen (an eval loop) can hold
+        on to the returned buffer."""
         if not self.is_default_arch():
             raise NotImplementedError("the fused HIP MLP implements the reference's default architecture "
                                       "(D=8, W=256, skips=[4], 63/27 inputs) only")
         dtype = dtype or self.mlp_dtype
         ps = self.flat_params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
         hit = self._packed_cache.get(dtype)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        buf = ops.pack_weights(ps[:12], ps[12:], dtype, out=hit[1] if hit is not None and hit[1].device == ps[0].device else None)
-        self._packed_cache[dtype] = (key, buf)
+        buf = ops.pack_weights(ps[:12], ps[12:], dtype, out=hit if hit is not None and hit.device == ps[0].device else None)
+        self._packed_cache[dtype] = buf
         return buf
 
     def packed_weights_bwd(self, dtype=None):
-        """W^T stream for the backward chain, cached like packed_weights()."""
+        """W^T stream for the backward chain (same policy as packed_weights)."""
         dtype = dtype or self.mlp_dtype
         ps = self.flat_params()[:12]
-        key = tuple((p.data_ptr(), p._version) for p in ps)
         hit = self._packed_cache.get(("bwd", dtype))
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        buf = ops.pack_weights_bwd(ps, dtype, out=hit[1] if hit is not None and hit[1].device == ps[0].device else None)
-        self._packed_cache[("bwd", dtype)] = (key, buf)
+        buf = ops.pack_weights_bwd(ps, dtype, out=hit if hit is not None and hit.device == ps[0].device else None)
+        self._packed_cache[("bwd", dtype)] = buf
         return buf
 
     def forward(self, x, sigma_only=False):

@@ -1,0 +1,63 @@
+"""Per-kernel micro-benchmark of the MLP kernels (HIP events, same process) for A/B-ing library builds:
+
+    NERFHIP_LIB_PATH=nerf_pl_amd/variants/libnerfhip_X.so python tools/kbench.py [--rays 1024] [--samples 192] [--dtype bf16]
+
+Prints one line: fwd (inference), fwd+save, bwd (chain+dW+reduce) average microseconds over `--reps` launches
+on random (not zero) data.  Individual backward kernels are split out by `rocprofv3 --kernel-trace`."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import nerf_oracle as O  # noqa: E402
+from nerf_pl_amd import ops  # noqa: E402
+from nerf_pl_amd.models import NeRF  # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(reps))
+    return sum(ts) / len(ts), ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=1024)
+    ap.add_argument("--samples", type=int, default=192)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    m = NeRF()
+    m.load_state_dict(O.make_params(101, 4.0, 0.2))
+    m.mlp_dtype = a.dtype
+    m = m.to(dev)
+    B, S = a.rays, a.samples
+    rays = O.make_rays(1, B, "blender").to(dev)
+    z = torch.sort(2 + 4 * torch.rand(B, S, device=dev), -1)[0]
+    packed = m.packed_weights(a.dtype)
+    pb = m.packed_weights_bwd(a.dtype)
+    acts = ops.alloc_acts(B * S, a.dtype, dev)
+    out = ops.mlp_fwd_rays(rays, z, packed, False, a.dtype, save=acts)
+    g_out = torch.randn_like(out)
+    f_avg, f_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, False, a.dtype), a.reps)
+    s_avg, s_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, False, a.dtype, save=acts), a.reps)
+    b_avg, b_min = timed(lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype), a.reps)
+    so_avg, so_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, True, a.dtype), a.reps)
+    print("%s %dx%d %s: fwd %.1f (min %.1f)  fwd_sigma %.1f  fwd+save %.1f (min %.1f)  bwd %.1f (min %.1f) us"
+          % (os.path.basename(os.environ.get("NERFHIP_LIB_PATH", "libnerfhip.so")), B, S, a.dtype, f_avg, f_min, so_avg, s_avg, s_min,
+             b_avg, b_min), flush=True)
+
+
+if __name__ == "__main__":
+    main()
