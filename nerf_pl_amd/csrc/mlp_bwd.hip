@@ -299,14 +299,25 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
 // ================================================================================================
 // Phase B: weight gradients
 // ================================================================================================
+// Jobs + their point-range splits.  A workgroup = (job, split).  Every job gets the SAME number of splits: a
+// workgroup's time is set by its iteration (tile) count, not by its bytes per tile (10-36 KiB) — measured: splits
+// proportional to bytes made the launch 20 % slower (651 vs 544 us at 1024x192) than uniform splits.
 struct DwJobTable {
     DwJob job[kNumDwJobs];
+    int nsplit[kNumDwJobs];
+    int soff[kNumDwJobs + 1];     // prefix sums: workgroup / partial-slab index of (job j, split 0)
 };
+#ifndef NERFHIP_DW_DEPTH
+#define NERFHIP_DW_DEPTH 4
+#endif
+#ifndef NERFHIP_DW_WGS
+#define NERFHIP_DW_WGS 512       // target workgroup count of the dW launch (2 rounds of 256 CUs at 1 workgroup/CU)
+#endif
 
 template <int PREC> struct DwTraits;
 template <> struct DwTraits<NERFHIP_BF16> {
     static constexpr int SPP = 1;            // 1 KiB pieces per slab
-    static constexpr int DEPTH = 4;          // ring stages
+    static constexpr int DEPTH = NERFHIP_DW_DEPTH;   // ring stages
     static constexpr int MAXP = 36;          // max pieces per stage ((16 + 20) slabs)
     static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
 };
@@ -319,7 +330,7 @@ template <> struct DwTraits<NERFHIP_F32> {
 
 template <int PREC>
 __global__ __launch_bounds__(512, 2)
-void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_t* __restrict__ acts_base,
+void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restrict__ acts_base,
                        const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
     constexpr int SPP = DwTraits<PREC>::SPP, DEPTH = DwTraits<PREC>::DEPTH, MAXP = DwTraits<PREC>::MAXP;
     constexpr int LPW = (MAXP + 7) / 8;                       // DMA instructions per wave per stage (padded)
@@ -329,7 +340,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int jid = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    int jid = 0;
+#pragma unroll
+    for (int j = 1; j < kNumDwJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
+    const int nsplit = jobs.nsplit[jid], split = (int)blockIdx.x - jobs.soff[jid];
     const DwJob jb = jobs.job[jid];
     const int n_ot = jb.dy_slabs / 2;
     const int n_xs = jb.x1_slabs + jb.x2_slabs;
@@ -391,8 +405,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int nsplit, int64_t ntiles, const uint8_
 
     for (int64_t it = 0; it < my_tiles; ++it) {
         // stage `it` landed (DEPTH-2 younger stages may still fly), everyone done with stage it-1
-        if (DEPTH == 4) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // 2 * LPW(5)
-        else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_assert(PREC != NERFHIP_BF16 || LPW == 5, "counted vmcnt below assumes 5 DMAs per wave per stage");
+        if (PREC == NERFHIP_BF16 && DEPTH == 4)      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (PREC == NERFHIP_BF16 && DEPTH == 3) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else                                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         issue_stage(it + DEPTH - 1);
         if (wave < n_ot) {
             const char* st_base = ring + (it % DEPTH) * STAGE_BYTES;
@@ -459,11 +475,14 @@ struct GradTable {
     float* b[12];
 };
 
-// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients
-__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, int nsplit, const float* __restrict__ slabs,
-                                                              GradTable G, int accumulate) {
+// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients.
+// One 256-thread block per (job, 32x32 tile): thread = one float4 (rows o..o+3 of one column) of the 1024-float
+// tile, summed over the job's splits with independent 16-B loads.
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, const float* __restrict__ slabs, GradTable G,
+                                                              int accumulate) {
     const int jid = blockIdx.y;
     const DwJob jb = jobs.job[jid];
+    const int nsplit = jobs.nsplit[jid], s0 = jobs.soff[jid];
     const int n_ot = jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
     const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
     const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, in
         if (m < 32) {
             float s = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) {
-                const float* sl = slabs + (size_t)(jid * nsplit + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
+                const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
                 s += sl[m] + sl[m + 32];
             }
             const int o = 32 * ot + m;
@@ -483,29 +502,40 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, in
         return;
     }
     if (xt >= n_xt) return;
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int lane = e >> 4, r = e & 15;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp)
-            s += slabs[(size_t)(jid * nsplit + sp) * kDwSlabFloats + ((size_t)(ot * kDwMaxXTiles + xt) * 64 + lane) * 16 + r];
-        const int h = lane >> 5, ncol = lane & 31;
-        const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int xi = 32 * xt + ncol;
-        int xs = xi >> 4;
-        const int i = xi & 15;
-        int enc, col0;
-        if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
-        else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
-        int col;
-        if (enc == 0) col = col0 + 16 * xs + i;
-        else {
-            const int ch = (enc == 1) ? xyz_slot_channel(xs, slab_nat_h(i), slab_nat_j(i))
-                                      : dir_slot_channel(xs, slab_nat_h(i), slab_nat_j(i));
-            col = ch < 0 ? -1 : col0 + ch;
-        }
-        if (o < n_out && col >= 0 && col < ldw) {
-            float* dst = G.w[jb.param] + (size_t)o * ldw + col;
-            *dst = accumulate ? *dst + s : s;
+    const int e4 = threadIdx.x;                        // floats 4*e4 .. 4*e4+3 of the tile: lane = e4>>2, r = 4*(e4&3)+k
+    const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
+                                                        ((size_t)(ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float4 v = src[(size_t)sp * (kDwSlabFloats / 4)];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int lane = e4 >> 2, rq = e4 & 3;
+    const int h = lane >> 5, ncol = lane & 31;
+    const int o0 = 32 * ot + 8 * rq + 4 * h;           // rows o0 .. o0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
+    const int xi = 32 * xt + ncol;
+    int xs = xi >> 4;
+    const int i = xi & 15;
+    int enc, col0;
+    if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
+    else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
+    int col;
+    if (enc == 0) col = col0 + 16 * xs + i;
+    else {
+        const int ch = (enc == 1) ? xyz_slot_channel(xs, slab_nat_h(i), slab_nat_j(i))
+                                  : dir_slot_channel(xs, slab_nat_h(i), slab_nat_j(i));
+        col = ch < 0 ? -1 : col0 + ch;
+    }
+    if (col >= 0 && col < ldw) {
+        const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = o0 + k;
+            if (o < n_out) {
+                float* dst = G.w[jb.param] + (size_t)o * ldw + col;
+                *dst = accumulate ? *dst + vals[k] : vals[k];
+            }
         }
     }
 }
@@ -548,17 +578,33 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
     return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
 }
 
-extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {
-    if (n_points <= 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+// NERFHIP_DW_WGS / 12 splits per job (fewer for few tiles)
+static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
+    using namespace nerfhip::mlp;
     const int64_t tiles = act_tiles(n_points, dtype);
-    int64_t s = 512 / nerfhip::mlp::kNumDwJobs;               // ~2 workgroups per CU over all jobs
-    if (s > tiles) s = tiles;
-    return (int)(s < 1 ? 1 : s);
+    int off = 0;
+    for (int j = 0; j < kNumDwJobs; ++j) {
+        int64_t ns = NERFHIP_DW_WGS / kNumDwJobs;
+        if (ns > tiles) ns = tiles;
+        if (ns < 1) ns = 1;
+        if (jt) {
+            jt->job[j] = kDwJobs[j];
+            jt->nsplit[j] = (int)ns;
+            jt->soff[j] = off;
+        }
+        off += (int)ns;
+    }
+    if (jt) jt->soff[kNumDwJobs] = off;
+    return off;
+}
+
+extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {      // total (job, split) workgroups / partial slabs
+    if (n_points <= 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    return dw_plan(n_points, dtype, nullptr);
 }
 
 extern "C" size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype) {
-    const int s = nerfhip_mlp_dw_splits(n_points, dtype);
-    return (size_t)s * nerfhip::mlp::kNumDwJobs * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+    return (size_t)nerfhip_mlp_dw_splits(n_points, dtype) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
 }
 
 extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
@@ -579,21 +625,20 @@ extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, 
         return NERFHIP_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = act_tiles(n, dtype);
-    const int nsplit = nerfhip_mlp_dw_splits(n, dtype);
     nerfhip::DwJobTable jt;
-    for (int i = 0; i < nerfhip::mlp::kNumDwJobs; ++i) jt.job[i] = nerfhip::mlp::kDwJobs[i];
+    const int nwg = dw_plan(n, dtype, &jt);
     if (dtype == NERFHIP_BF16) {
         hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16>, dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, out,
                            n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nerfhip::mlp::kNumDwJobs * nsplit), dim3(512), 0, s, jt,
-                           nsplit, tiles, (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, tiles,
+                           (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     } else {
         hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, out,
                            n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nerfhip::mlp::kNumDwJobs * nsplit), dim3(512), 0, s, jt,
-                           nsplit, tiles, (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, tiles,
+                           (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     }
     hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel, dim3(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs),
-                       dim3(256), 0, s, jt, nsplit, (const float*)dw_workspace, G, accumulate);
+                       dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
     return nerfhip_launch_status();
 }
