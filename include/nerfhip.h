@@ -142,6 +142,13 @@ int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void*
                     void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
                     int accumulate, int dtype, nerfhip_stream_t stream);
 
+/* ---- N2. MSELoss.forward + psnr + backward seed  (losses.py:9-14, metrics.py:4-13, train.py:103-117) ----
+ * rgb_coarse, rgb_fine (NULL when N_importance == 0), target: n = 3*rays floats each.
+ * out3 = [loss, psnr of the fine (else coarse) image, its mse];  g_coarse / g_fine (NULL ok) receive
+ * d loss / d rgb = 2 (rgb - target) / n.  One launch, deterministic reduction order.                        */
+int nerfhip_mse_psnr(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, float* out3,
+                     float* g_coarse, float* g_fine, nerfhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ SIGNATURES = {
     "nerfhip_mlp_dy_bytes": [_i64, _int],
     "nerfhip_mlp_dw_splits": [_i64, _int],
     "nerfhip_mlp_dw_workspace_bytes": [_i64, _int],
+    "nerfhip_mse_psnr": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
 }

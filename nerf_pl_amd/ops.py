@@ -157,6 +157,7 @@ class _Composite(torch.autograd.Function):
                                                 ptr(opacity), B, S, stream_ptr()), "nerfhip_composite_fwd")
         ctx.save_for_backward(raw, z, rays, noise)
         ctx.cfg = (raw_ch, float(noise_std), int(bool(white_back)))
+        ctx.set_materialize_grads(False)     # unused outputs (weights/depth/opacity) arrive as None, not as zero fills
         if raw_ch == 4:
             return weights, opacity, rgb, depth
         return weights, opacity
@@ -184,6 +185,37 @@ def composite(raw, z, rays, noise=None, noise_std=0.0, white_back=False):
     if noise_std == 0:
         noise = None
     return _Composite.apply(raw, z, rays, noise, float(noise_std), bool(white_back))
+
+
+# ------------------------------------------------------------------------------- loss + PSNR (N2)
+class _MsePsnr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_c, rgb_f, target):
+        require_gpu(rgb_c, rgb_f, target)
+        rgb_c, target = _c(rgb_c), _c(target)
+        rgb_f = _c(rgb_f) if rgb_f is not None else None
+        n = target.numel()
+        if rgb_c.numel() != n or (rgb_f is not None and rgb_f.numel() != n):
+            raise ValueError("mse_psnr: shape mismatch")
+        out3 = torch.empty(3, device=target.device, dtype=torch.float32)
+        g_c = torch.empty_like(rgb_c)
+        g_f = torch.empty_like(rgb_f) if rgb_f is not None else None
+        check(_lib.load().nerfhip_mse_psnr(ptr(rgb_c), ptr(rgb_f), ptr(target), n, ptr(out3), ptr(g_c), ptr(g_f), stream_ptr()),
+              "nerfhip_mse_psnr")
+        ctx.save_for_backward(g_c, g_f)
+        ctx.mark_non_differentiable(out3)
+        return out3[0], out3
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out3):
+        g_c, g_f = ctx.saved_tensors
+        return g_c * g_loss, (g_f * g_loss if g_f is not None else None), None
+
+
+def mse_psnr(rgb_coarse, rgb_fine, target):
+    """MSELoss.forward (losses.py:9-14) + psnr (metrics.py:4-13) + d loss/d rgb in one launch.
+    Returns (loss [differentiable scalar], out3 = [loss, psnr, mse] detached)."""
+    return _MsePsnr.apply(rgb_coarse, rgb_fine, target)
 
 
 # ------------------------------------------------------------------------------- MLP (a3, a4, a6)
@@ -218,6 +250,38 @@ def pack_weights(weights, biases, dtype, out=None):
     bp = (ctypes.c_void_p * 12)(*[k[1].data_ptr() for k in keep])
     check(_lib.load().nerfhip_mlp_pack_weights(wp, bp, ptr(out), code, stream_ptr()), "nerfhip_mlp_pack_weights")
     return out
+
+
+_SIZE_CACHE = {}
+
+
+def packed_bwd_bytes(dtype):
+    return int(_lib.load().nerfhip_mlp_packed_bwd_bytes(mlp_dtype_code(dtype)))
+
+
+def pack_arg_tables(weights, biases):
+    """Validate the 12 (weight, bias) tensors once and return ctypes pointer tables (wp, bp) for the pack entry points."""
+    if len(weights) != 12 or len(biases) != 12:
+        raise ValueError("need 12 weights and 12 biases")
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        require_gpu(w, b)
+        if tuple(w.shape) != PARAM_SHAPES[i] or tuple(b.shape) != (PARAM_SHAPES[i][0],):
+            raise NerfHipError("fused MLP supports the reference default architecture only "
+                               "(D=8, W=256, skips=[4], in 63/27); got %s for %s" % (tuple(w.shape), PARAM_ORDER[i]))
+        if not (w.is_contiguous() and b.is_contiguous()):
+            raise NerfHipError("NeRF parameters must be contiguous")
+    wp = (ctypes.c_void_p * 12)(*[w.data_ptr() for w in weights])
+    bp = (ctypes.c_void_p * 12)(*[b.data_ptr() for b in biases])
+    return wp, bp
+
+
+def pack_weights_raw(wp, bp, out, dtype):
+    check(_lib.load().nerfhip_mlp_pack_weights(wp, bp, ptr(out), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_pack_weights")
+
+
+def pack_weights_bwd_raw(wp, out, dtype):
+    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), mlp_dtype_code(dtype), stream_ptr()),
+          "nerfhip_mlp_pack_weights_bwd")
 
 
 def alloc_acts(n_points, dtype, device):

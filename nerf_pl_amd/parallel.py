@@ -52,20 +52,21 @@ class GradSync:
     """Average gradients across ranks: one all-reduce per model on its flat gradient buffer when the
     HIP backward produced one, else a flatten/all-reduce/unflatten of the parameter grads."""
 
-    def __init__(self, models, group=None):
+    def __init__(self, models, group=None, force=False):
         self.models = list(models)
         self.group = group
+        self.force = force          # run the collectives even at world size 1 (tests the RCCL path on one GPU)
 
     def sync(self):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force):
             return
         world = dist.get_world_size(self.group)
         works = []
         for m in self.models:
             flat = getattr(m, "_flat_grad", None)
             params = [p for p in m.parameters() if p.grad is not None]
-            if flat is not None and params and all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
-                                                   for p in params):
+            if (flat is not None and params and params[0].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+                    and params[-1].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()):
                 works.append((dist.all_reduce(flat, group=self.group, async_op=True), flat, None))
             elif params:
                 buf = torch.cat([p.grad.reshape(-1) for p in params])

@@ -74,8 +74,12 @@ class NeRFSystem(_Base):
         """Adam(lr, eps=1e-8, weight_decay) over all models + MultiStepLR (utils/__init__.py:10-53)."""
         hp = self.hp
         params = [p for m in self.models for p in m.parameters()]
-        self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0),
-                                          fused=params[0].is_cuda)
+        if params[0].is_cuda and getattr(hp, 'flat_optimizer', True):
+            from .optim import FlatAdam           # same Adam math on one flat tensor per model (2 launches, not 48 tensors)
+            self.optimizer = FlatAdam(self.models, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0))
+        else:
+            self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0),
+                                              fused=params[0].is_cuda)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(getattr(hp, 'decay_step', [20])),
                                                          gamma=getattr(hp, 'decay_gamma', 0.1))
         return [self.optimizer], [scheduler]
@@ -86,10 +90,13 @@ class NeRFSystem(_Base):
         rays, rgbs = self.decode_batch(batch)
         results = self(rays)
         log['train/loss'] = loss = self.loss(results, rgbs)
-        typ = 'fine' if 'rgb_fine' in results else 'coarse'
-        with torch.no_grad():
-            psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
-            log['train/psnr'] = psnr_
+        if getattr(self.loss, 'last', None) is not None:      # fused loss kernel already produced the PSNR
+            psnr_ = self.loss.last[1]
+        else:
+            typ = 'fine' if 'rgb_fine' in results else 'coarse'
+            with torch.no_grad():
+                psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
+        log['train/psnr'] = psnr_
         return {'loss': loss, 'progress_bar': {'train_psnr': psnr_}, 'log': log}
 
     def validation_step(self, batch, batch_nb):
@@ -125,3 +132,54 @@ def fit(system, batches, grad_sync=None, steps=None):
         opt.step()
         losses.append(out['loss'].detach())
     return losses
+
+
+class GraphedTrainStep:
+    """One full training step (training_step -> backward -> [gradient all-reduce] -> optimizer.step) replayed as a
+    hipGraph (`torch.cuda.CUDAGraph`).
+
+    The step is ~45 launches and ~1.6 ms of GPU work; issuing it eagerly costs 1.4-1.6 ms of host time (autograd
+    engine, ctypes, optimizer bookkeeping), i.e. the host is as slow as the GPU.  libnerfhip launches on torch's
+    current stream, allocates nothing and never synchronises, so the whole step captures; replay costs ~15 us of host
+    time.  The first `warmup` calls run eagerly on the real batches (they are ordinary training steps), the next call
+    captures and then replays.  A learning-rate change (scheduler) triggers a re-capture.
+    Outputs are static tensors overwritten by every replay (clone what you keep)."""
+
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3):
+        self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
+        self.warmup = warmup
+        self.calls = 0
+        self.graph = None
+        self.static_batch = None
+        self.static_out = None
+        self.captured_lr = None
+
+    def _eager(self, batch):
+        out = self.system.training_step(batch, self.calls)
+        self.opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        if self.grad_sync is not None:
+            self.grad_sync.sync()
+        self.opt.step()
+        return out
+
+    def _capture(self, batch):
+        self.static_batch = {k: v.clone() for k, v in batch.items()}
+        self.captured_lr = get_learning_rate(self.opt)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self._eager(self.static_batch)
+
+    def __call__(self, batch):
+        self.calls += 1
+        if self.calls <= self.warmup:
+            return self._eager(batch)
+        if (self.graph is None or get_learning_rate(self.opt) != self.captured_lr
+                or any(batch[k].shape != self.static_batch[k].shape for k in batch)):
+            torch.cuda.synchronize()
+            self._capture(batch)
+        else:
+            for k, v in batch.items():
+                self.static_batch[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

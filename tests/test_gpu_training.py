@@ -119,3 +119,120 @@ def test_fused_adam_updates_are_seen(dev):
     assert (after - before).abs().max().item() > 1e-3, "render did not change after 12 fused-Adam steps"
     ls = [l.item() for l in losses]
     assert min(ls[-3:]) < ls[0], ls            # the optimizer is acting on the weights the kernels see
+
+
+def test_fused_mse_psnr_matches_reference_formulas(dev):
+    """nerfhip_mse_psnr == losses.py:9-14 + metrics.py:4-13 (+ autograd of the MSE), with and without a fine image."""
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for B in (1, 7, 1024, 5000):
+        c = torch.rand(B, 3, generator=g)
+        f = torch.rand(B, 3, generator=g)
+        t = torch.rand(B, 3, generator=g)
+        for fine in (f, None):
+            cc = c.clone().requires_grad_(True)
+            ff = fine.clone().requires_grad_(True) if fine is not None else None
+            ref = torch.nn.functional.mse_loss(cc, t) + (torch.nn.functional.mse_loss(ff, t) if ff is not None else 0)
+            ref.backward()
+            ref_psnr = -10 * torch.log10(torch.mean(((ff if ff is not None else cc).detach() - t) ** 2))
+            cd = c.to(dev).requires_grad_(True)
+            fd = fine.to(dev).requires_grad_(True) if fine is not None else None
+            loss, out3 = ops.mse_psnr(cd, fd, t.to(dev))
+            (loss * 3.0).backward()                              # upstream factor must be applied
+            assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+            assert abs(out3[1].item() - ref_psnr.item()) <= 1e-4
+            assert torch.allclose(cd.grad.cpu(), 3.0 * cc.grad, rtol=1e-6, atol=1e-9)
+            if fine is not None:
+                assert torch.allclose(fd.grad.cpu(), 3.0 * ff.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_flat_adam_equals_per_tensor_adam(dev):
+    """FlatAdam (one flat tensor per model, grads adopted from the dW-reduce buffer) == torch Adam over the 48 tensors."""
+    from argparse import Namespace
+    from nerf_pl_amd.system import NeRFSystem, fit
+    rays = O.make_rays(3, 192, "blender").to(dev)
+    tgt = torch.rand(192, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    finals = []
+    for flat in (True, False):
+        hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=0.0, noise_std=0.0, chunk=1024 * 32,
+                       loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True,
+                       flat_optimizer=flat)
+        system = NeRFSystem(hp)
+        system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
+        for m in system.models:
+            m.mlp_dtype = "fp32"
+        system = system.to(dev)
+        torch.manual_seed(0)
+        fit(system, [{"rays": rays, "rgbs": tgt}] * 4)
+        assert type(system.optimizer).__name__ == ("FlatAdam" if flat else "Adam")
+        finals.append({k: v.detach().cpu().clone() for k, v in system.state_dict().items()})
+    assert finals[0].keys() == finals[1].keys()
+    for k in finals[0]:
+        assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-5, atol=1e-7), k
+    # the flat path really moved the weights
+    assert not torch.equal(finals[0]["nerf_fine.sigma.weight"], O.make_params(6, 4.0, 0.2)["sigma.weight"])
+
+
+def test_graphed_train_step_equals_eager(dev):
+    """hipGraph replay of the whole training step (GraphedTrainStep) == eager issue, step for step
+    (perturb=0: no RNG in the math; same kernels, same inputs => same weights)."""
+    from argparse import Namespace
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    gen = torch.Generator().manual_seed(1)
+    batches = [{"rays": O.make_rays(10 + i, 128, "blender").to(dev), "rgbs": torch.rand(128, 3, generator=gen).to(dev)}
+               for i in range(8)]
+    finals, losses = [], []
+    for graphed in (False, True):
+        hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=0.0, noise_std=0.0, chunk=1024 * 32,
+                       loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True)
+        system = NeRFSystem(hp)
+        system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
+        for m in system.models:
+            m.mlp_dtype = "bf16"
+        system = system.to(dev)
+        (opt,), _ = system.configure_optimizers()
+        stepper = GraphedTrainStep(system, opt, warmup=2 if graphed else 10 ** 9)
+        ls = []
+        for b in batches:
+            ls.append(stepper(b)["loss"].item())
+        assert (stepper.graph is not None) == graphed
+        losses.append(ls)
+        finals.append({k: v.detach().cpu().clone() for k, v in system.state_dict().items()})
+    assert losses[0] == pytest.approx(losses[1], rel=1e-5), (losses[0], losses[1])
+    for k in finals[0]:
+        assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-5, atol=1e-7), k
+
+
+def test_graphed_step_with_rccl_allreduce_world1(dev):
+    """The N>1 training step (gradient all-reduce on the flat buffers through backend nccl = RCCL) inside the hipGraph
+    capture, exercised on one GPU with a world_size-1 process group (8-GPU runs belong to the driver)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from argparse import Namespace
+    from nerf_pl_amd.parallel import GradSync
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32,
+                       loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True)
+        system = NeRFSystem(hp)
+        for m in system.models:
+            m.mlp_dtype = "bf16"
+        system = system.to(dev)
+        (opt,), _ = system.configure_optimizers()
+        sync = GradSync(system.models, force=True)
+        stepper = GraphedTrainStep(system, opt, grad_sync=sync, warmup=2)
+        batch = {"rays": O.make_rays(1, 256, "blender").to(dev), "rgbs": torch.rand(256, 3, device=dev)}
+        ls = [stepper(batch)["loss"].item() for _ in range(8)]
+        assert stepper.graph is not None
+        assert all(torch.isfinite(torch.tensor(ls))) and min(ls[-3:]) < ls[0], ls
+    finally:
+        dist.destroy_process_group()
