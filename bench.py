@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="train", choices=["train", "render"])
+    ap.add_argument("--mode", default="train", choices=["train", "render", "eval"])
+    ap.add_argument("--image-rays", type=int, default=640000, help="--mode eval: rays per image (800x800), sharded over ranks")
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=128)
@@ -177,7 +178,20 @@ def main():
             torch.cuda.synchronize()
             return eager_step()
 
-    step = train_step if a.mode == "train" else render_step
+    # --mode eval (BASELINE.json configs[4]): one step = one full 800x800 image through eval.py's batched_inference
+    # contract (32768-ray chunks, test_time: sigma-only coarse pass), each chunk a hipGraph replay; the ray list is
+    # sharded contiguously over the ranks (strong scaling) and the finished pixels are all-gathered.
+    eval_state = {}
+    if a.mode == "eval":
+        from nerf_pl_amd.inference import GraphRenderer
+        from nerf_pl_amd.parallel import render_sharded
+        eval_state["rays"] = O.make_rays(77, a.image_rays, "blender").to(dev)
+        eval_state["gr"] = GraphRenderer(models, emb, S, N, False, True)
+
+    def eval_step():
+        return render_sharded(eval_state["gr"], eval_state["rays"], keys=("rgb_fine", "depth_fine"))
+
+    step = train_step if a.mode == "train" else (eval_step if a.mode == "eval" else render_step)
     for _ in range(max(a.warmup, 5) if a.mode == "train" else a.warmup):     # >= 5: 3 eager + capture + 1 replay
         step()
 
@@ -261,19 +275,26 @@ def main():
                                      "avg_launch_us": round(bms * 1e3, 2)}
             del acts, out_f, g_out
 
-        total_rays = world * B * a.steps
+        total_rays = (a.image_rays if a.mode == "eval" else world * B) * a.steps
         out = {
             "metric": ("rays/sec (64+128 samples), full training step: render_rays fwd + MSE + bwd + grad all-reduce + Adam"
                        if a.mode == "train" else
+                       "rays/sec (64+128 samples), full-image inference (eval.py batched_inference, test_time, 32768-ray hipGraph chunks)"
+                       if a.mode == "eval" else
                        "rays/sec (64+128 samples), render_rays forward only (train-mode: coarse+fine rgb)"),
             "value": round(total_rays / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if a.mode == "eval" else "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[2]: %d rays/GPU x (%d+%d) samples, NeRF D8 W256 coarse+fine, perturb=1 "
-                                   "noise_std=0 white_back, %s MFMA MLP, mode=%s" % (B, S, N, a.dtype, a.mode),
-                       "rays_per_gpu": B, "N_samples": S, "N_importance": N,
+            "config": {"workload": ("configs[4]: %d-ray image in 32768-ray chunks x (%d+%d) samples, test_time, NeRF D8 W256 "
+                                    "coarse(sigma-only)+fine, %s MFMA MLP, mode=eval" % (a.image_rays, S, N, a.dtype))
+                                   if a.mode == "eval" else
+                                   ("configs[2]: %d rays/GPU x (%d+%d) samples, NeRF D8 W256 coarse+fine, perturb=1 "
+                                    "noise_std=0 white_back, %s MFMA MLP, mode=%s" % (B, S, N, a.dtype, a.mode)),
+                       "rays_per_gpu": (a.image_rays // world if a.mode == "eval" else B), "N_samples": S, "N_importance": N,
                        "issue": ("hipGraph replay of the whole step" if (a.mode == "train" and state["graphed"] is not None
-                                                                         and state["graphed"].graph is not None) else "eager"),
+                                                                         and state["graphed"].graph is not None)
+                                 else "hipGraph replay per 32768-ray chunk" if a.mode == "eval" else "eager"),
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if world > 1 and a.mode == "train" else "")},
         }
         out.update(extra)

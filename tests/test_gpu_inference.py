@@ -67,3 +67,19 @@ def test_full_chunk_properties_bf16(dev):
     assert (full["opacity_fine"] >= 0).all() and (full["opacity_fine"] <= 1 + 1e-5).all()
     assert (full["rgb_fine"] >= -1e-5).all() and (full["rgb_fine"] <= 1 + 1e-4).all()
     assert (full["depth_fine"] >= 0).all() and (full["depth_fine"] <= 6.0 + 1e-3).all()
+
+
+def test_empty_and_single_ray_batches(dev):
+    """Edge sizes through the whole path: B = 0 (empty chunk after sharding) and B = 1."""
+    from nerf_pl_amd.models import render_rays
+    params = [O.make_params(41, 6.0, 0.3), O.make_params(42, 6.0, 0.3)]
+    ms, emb = build_models(params, dev, "fp32")
+    with torch.no_grad():
+        out = render_rays(ms, emb, torch.zeros(0, 8, device=dev), 64, False, 0, 0, 64, 32768, True, test_time=True)
+    assert out["rgb_fine"].shape == (0, 3) and out["opacity_coarse"].shape == (0,)
+    rays = O.make_rays(2, 1, "blender")
+    ref = O.render_rays(params, rays, 64, False, 0, 0, 64, True, False)
+    with torch.no_grad():
+        got = render_rays(ms, emb, rays.to(dev), 64, False, 0, 0, 64, 32768, True)
+    for k, v in ref.items():
+        assert torch.allclose(got[k].cpu(), v, rtol=1e-4, atol=1e-4), k
