@@ -149,6 +149,23 @@ int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void*
 int nerfhip_mse_psnr(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, float* out3,
                      float* g_coarse, float* g_fine, nerfhip_stream_t stream);
 
+/* ---- N1. ray generation  (datasets/ray_utils.py:5-94; consumers blender.py:37-69, llff.py:236-253) --------
+ * get_ray_directions: dirs (H,W,3) = ((i-W/2)/focal, -(j-H/2)/focal, -1), i = column, j = row.
+ * get_rays: rays_d = normalise(directions @ c2w[:, :3].T), rays_o = c2w[:, 3]; c2w (3,4) row-major DEVICE array.
+ * get_ndc_rays: shift to the near plane and project (forward-facing LLFF scenes).  `focal` is a double: the
+ * reference forms -1/(W/(2 focal)) in Python double precision before it meets the fp32 tensors.                */
+int nerfhip_ray_directions(float* dirs, int H, int W, double focal, nerfhip_stream_t stream);
+int nerfhip_get_rays(const float* directions, const float* c2w, float* rays_o, float* rays_d, int64_t n,
+                     nerfhip_stream_t stream);
+int nerfhip_ndc_rays(int H, int W, double focal, float near, const float* rays_o, const float* rays_d, float* out_o,
+                     float* out_d, int64_t n, nerfhip_stream_t stream);
+/* All of the above fused, for a batch of pixels: rays (n,8) = [o d near far] of global pixel ids
+ * `pixel_ids[r]` = image*H*W + row*W + col (or first_pixel + r when pixel_ids is NULL) under poses
+ * c2w (n_images,3,4); use_ndc applies get_ndc_rays with the near plane at ndc_near_plane (llff.py uses 1.0). */
+int nerfhip_gen_rays(const float* c2w, const int64_t* pixel_ids, int64_t first_pixel, int64_t n, int H, int W,
+                     double focal, float near, float far, int use_ndc, float ndc_near_plane, float* rays,
+                     nerfhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

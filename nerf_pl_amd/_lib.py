@@ -46,6 +46,11 @@ SIGNATURES = {
     "nerfhip_mlp_dy_bytes": [_i64, _int],
     "nerfhip_mlp_dw_splits": [_i64, _int],
     "nerfhip_mlp_dw_workspace_bytes": [_i64, _int],
+    "nerfhip_ray_directions": [_c_void_p, _int, _int, ctypes.c_double, _c_void_p],
+    "nerfhip_get_rays": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
+    "nerfhip_ndc_rays": [_int, _int, ctypes.c_double, _f32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
+    "nerfhip_gen_rays": [_c_void_p, _c_void_p, _i64, _i64, _int, _int, ctypes.c_double, _f32, _f32, _int, _f32, _c_void_p,
+                         _c_void_p],
     "nerfhip_mse_psnr": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],

@@ -213,6 +213,25 @@ def main():
     G["gr_full_f_rgb.0.weight"] = mf.rgb[0].weight.grad.clone()
     G["gr_full_f_xyz_encoding_1.0.bias"] = getattr(mf, "xyz_encoding_1")[0].bias.grad.clone()
 
+    # ---------------------------------------------------------------- 7. ray geometry (datasets/ray_utils.py), N1
+    ru = ref_shim.load_reference_ray_utils()
+    for tag, (H, W, focal, pose_seed) in {"blender": (20, 24, 27.7777, 31), "llff": (19, 25, 21.5, 32)}.items():
+        c2w = O.make_pose(pose_seed)
+        dirs = ru.get_ray_directions(H, W, focal)
+        ro, rd = ru.get_rays(dirs, c2w)
+        G[f"rg_{tag}_cfg"] = torch.tensor([H, W, focal, pose_seed], dtype=torch.float64)
+        G[f"rg_{tag}_dirs"] = dirs
+        G[f"rg_{tag}_o"] = ro.contiguous()
+        G[f"rg_{tag}_d"] = rd.contiguous()
+        assert torch.equal(O.get_ray_directions(H, W, focal), dirs)
+        oo, od = O.get_rays(dirs, c2w)
+        assert torch.allclose(od, rd, rtol=0, atol=1e-7) and torch.equal(oo, ro)
+        if tag == "llff":                                  # forward-facing scenes: NDC with the near plane at 1.0 (llff.py:236-239)
+            no, nd = ru.get_ndc_rays(H, W, focal, 1.0, ro, rd)
+            G["rg_llff_ndc_o"], G["rg_llff_ndc_d"] = no.contiguous(), nd.contiguous()
+            po, pd = O.get_ndc_rays(H, W, focal, 1.0, ro, rd)
+            assert torch.equal(po, no) and torch.equal(pd, nd)
+
     out = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in G.items()}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     np.savez_compressed(OUT, **out)

@@ -317,3 +317,47 @@ def grad_digest(g):
         head = torch.cat([head, torch.zeros(8 - head.numel(), dtype=torch.float64)])
         tail = torch.cat([tail, torch.zeros(8 - tail.numel(), dtype=torch.float64)])
     return torch.cat([f.sum()[None], f.norm()[None], head, tail]).float()
+
+
+# ----------------------------------------------------------------------------- ray geometry (N1)
+# Restatement of reference datasets/ray_utils.py (pinned by tests/golden: "rg_*" vectors minted from the real file).
+def get_ray_directions(H, W, focal):
+    """datasets/ray_utils.py:5-24: pixel (i = column, j = row) -> camera-space direction
+    ((i - W/2)/focal, -(j - H/2)/focal, -1), no +0.5 pixel centring.  (H, W, 3) fp32."""
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    return torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones_like(i)], -1)
+
+
+def get_rays(directions, c2w):
+    """datasets/ray_utils.py:27-52: rotate by c2w[:, :3], normalise, origin = c2w[:, 3].  -> (H*W,3) o, (H*W,3) d."""
+    rays_d = directions @ c2w[:, :3].T
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    rays_o = c2w[:, 3].expand(rays_d.shape)
+    return rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+
+
+def get_ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """datasets/ray_utils.py:55-94: shift origins to the near plane, project to NDC."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    ox_oz = rays_o[..., 0] / rays_o[..., 2]
+    oy_oz = rays_o[..., 1] / rays_o[..., 2]
+    o0 = -1. / (W / (2. * focal)) * ox_oz
+    o1 = -1. / (H / (2. * focal)) * oy_oz
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - ox_oz)
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - oy_oz)
+    d2 = 1 - o2
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def make_pose(seed):
+    """A deterministic camera-to-world (3,4): random rotation (QR of a PCG64 gaussian matrix, det +1) and an origin
+    ~4 units from the scene centre, like the Blender cameras."""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    t = rng.standard_normal(3)
+    t = 4.0 * t / np.linalg.norm(t)
+    return torch.from_numpy(np.concatenate([q, t[:, None]], 1).astype(np.float32))

@@ -49,6 +49,25 @@ def _load(name, relpath):
 _cache = {}
 
 
+def load_reference_ray_utils():
+    """`datasets/ray_utils.py` of the reference, unmodified; its only missing import is kornia.create_meshgrid
+    (pixel-coordinate grid, x = column, y = row, fp32), replaced by a 5-line stand-in."""
+    import torch
+    if "ray_utils" not in _cache:
+        if "kornia" not in sys.modules:
+            kornia = types.ModuleType("kornia")
+
+            def create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=torch.float32):
+                assert not normalized_coordinates
+                ys, xs = torch.meshgrid(torch.arange(height, dtype=dtype), torch.arange(width, dtype=dtype), indexing="ij")
+                return torch.stack([xs, ys], -1)[None]
+
+            kornia.create_meshgrid = create_meshgrid
+            sys.modules["kornia"] = kornia
+        _cache["ray_utils"] = _load("_ref_ray_utils", "datasets/ray_utils.py")
+    return _cache["ray_utils"]
+
+
 def load_reference():
     """Returns (ref_nerf_module, ref_rendering_module) loaded from the reference tree
     under private module names (so they never shadow our own `models` package)."""
