@@ -136,7 +136,7 @@ size_t nerfhip_mlp_packed_bwd_bytes(int dtype);
 int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
                                  nerfhip_stream_t stream);
 size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype);
-int nerfhip_mlp_dw_splits(int64_t n_points, int dtype);
+int nerfhip_mlp_dw_splits(int64_t n_points, int dtype);   /* total (job, point-split) workgroups = partial slabs */
 size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype);
 int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
                     void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,

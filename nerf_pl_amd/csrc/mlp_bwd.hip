@@ -349,7 +349,19 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restric
     const int n_xs = jb.x1_slabs + jb.x2_slabs;
     const int n_xt = n_xs / 2;
     const int npieces = (jb.dy_slabs + n_xs) * SPP;
+#ifndef NERFHIP_DW_BLOCKED
+#define NERFHIP_DW_BLOCKED 1
+#endif
+#if NERFHIP_DW_BLOCKED
+    // contiguous tile range per split (consecutive iterations stay inside the same 2 MiB pages: a tile block is
+    // 167 KiB; the strided assignment touched 2-3 new pages per iteration per workgroup)
+    const int64_t per = (ntiles + nsplit - 1) / nsplit;
+    const int64_t t_first = (int64_t)split * per;
+    const int64_t my_tiles = (t_first >= ntiles) ? 0 : ((ntiles - t_first < per) ? ntiles - t_first : per);
+#else
+    const int64_t t_first = split;
     const int64_t my_tiles = (ntiles - split + nsplit - 1) / nsplit;   // tiles split, split+nsplit, ...
+#endif
     const unsigned lds_base = (unsigned)(uintptr_t)ring;
 
     // stage image: [dy slabs][x1 slabs][x2 slabs], each slab SPP 1 KiB pieces at 1 KiB pitch.  The DMA writes
@@ -361,7 +373,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restric
     const int dma_off_even = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + (lane >> 1)) * 16 : lane * 16;
     const int dma_off_odd = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + ((lane ^ 8) >> 1)) * 16 : lane * 16;
     auto issue_stage = [&](int64_t it) {
-        int64_t T = split + (it < my_tiles ? it : my_tiles - 1) * nsplit;   // past the end: re-fetch (keeps counts uniform)
+        int64_t T = t_first + (it < my_tiles ? it : my_tiles - 1) * (NERFHIP_DW_BLOCKED ? 1 : nsplit);   // past the end: re-fetch
         if (T >= ntiles) T = ntiles - 1;
         const uint8_t* abase = acts_base + (size_t)T * act_tile_bytes(PREC);
         const uint8_t* dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);

@@ -19,6 +19,9 @@
 #ifndef NERFHIP_TILE_SCHED_BARRIER
 #define NERFHIP_TILE_SCHED_BARRIER 0
 #endif
+#ifndef NERFHIP_FAST_SINCOS
+#define NERFHIP_FAST_SINCOS 1   // bf16 kernels only; the fp32 (parity) kernels always use sincosf
+#endif
 #ifndef NERFHIP_PF2
 #define NERFHIP_PF2 2      // prefetch depth of the 2-waves-per-SIMD (256-register) bf16 kernels
 #endif
@@ -297,14 +300,36 @@ __device__ __forceinline__ void encode_slots(const float (&v)[3], int h, Slab* o
     float vs[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) vs[c] = h ? 2.0f * v[c] : v[c];
+    if constexpr (sizeof(Slab) == 16 && NERFHIP_FAST_SINCOS) {
+        // bf16 kernels: hardware v_sin_f32 / v_cos_f32 (argument in REVOLUTIONS) instead of libm's sincosf, whose
+        // inlined Payne-Hanek path is ~80 instructions x 42 calls per lane.  x/2pi is formed once per channel as a
+        // hi+lo pair (two-constant product), scaled by the exact power of two and reduced with v_fract before the lo
+        // part is added: |error| ~ 1e-6, three orders below the bf16 rounding applied to the result.
+        constexpr float kInv2PiHi = 0.15915494f, kInv2PiLo = 6.4206297e-9f;
+        float rh[3], rl[3];
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-        const int i = p / 3, c = p % 3;
-        const float arg = vs[c] * (float)(1 << (2 * i));   // x * 2^(2i+h): exact power-of-two scaling
-        float s, co;
-        sincosf(arg, &s, &co);
-        slots[2 * p] = s;
-        slots[2 * p + 1] = co;
+        for (int c = 0; c < 3; ++c) {
+            rh[c] = vs[c] * kInv2PiHi;
+            rl[c] = __builtin_fmaf(vs[c], kInv2PiHi, -rh[c]) + vs[c] * kInv2PiLo;
+        }
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+            const int i = p / 3, c = p % 3;
+            const float sc = (float)(1 << (2 * i));
+            const float t = __builtin_amdgcn_fractf(rh[c] * sc) + rl[c] * sc;
+            slots[2 * p] = __builtin_amdgcn_sinf(t);
+            slots[2 * p + 1] = __builtin_amdgcn_cosf(t);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+            const int i = p / 3, c = p % 3;
+            const float arg = vs[c] * (float)(1 << (2 * i));   // x * 2^(2i+h): exact power-of-two scaling
+            float s, co;
+            sincosf(arg, &s, &co);
+            slots[2 * p] = s;
+            slots[2 * p + 1] = co;
+        }
     }
 #pragma unroll
     for (int idx = 2 * NPAIR; idx < 8 * SLABS; ++idx) {

@@ -135,29 +135,40 @@ def fit(system, batches, grad_sync=None, steps=None):
 
 
 class GraphedTrainStep:
-    """One full training step (training_step -> backward -> [gradient all-reduce] -> optimizer.step) replayed as a
-    hipGraph (`torch.cuda.CUDAGraph`).
+    """One full training step (training_step -> backward -> [gradient all-reduce] -> optimizer.step) replayed as
+    hipGraphs (`torch.cuda.CUDAGraph`).
 
     The step is ~45 launches and ~1.6 ms of GPU work; issuing it eagerly costs 1.4-1.6 ms of host time (autograd
     engine, ctypes, optimizer bookkeeping), i.e. the host is as slow as the GPU.  libnerfhip launches on torch's
     current stream, allocates nothing and never synchronises, so the whole step captures; replay costs ~15 us of host
     time.  The first `warmup` calls run eagerly on the real batches (they are ordinary training steps), the next call
     captures and then replays.  A learning-rate change (scheduler) triggers a re-capture.
+
+    With a `grad_sync` (N > 1 ranks) the step is captured as TWO graphs — [forward + backward] and [optimizer] — with
+    the RCCL all-reduce of the two flat gradient buffers issued eagerly in between (two collective calls per step;
+    `sync_in_graph=True` captures them inside a single graph instead, which RCCL supports but which is only
+    exercised at world size 1 here).
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
-    def __init__(self, system, optimizer, grad_sync=None, warmup=3):
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False):
         self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
         self.warmup = warmup
+        self.sync_in_graph = sync_in_graph
         self.calls = 0
         self.graph = None
+        self.graph_opt = None
         self.static_batch = None
         self.static_out = None
         self.captured_lr = None
 
-    def _eager(self, batch):
+    def _fwd_bwd(self, batch):
         out = self.system.training_step(batch, self.calls)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
+        return out
+
+    def _eager(self, batch):
+        out = self._fwd_bwd(batch)
         if self.grad_sync is not None:
             self.grad_sync.sync()
         self.opt.step()
@@ -167,8 +178,16 @@ class GraphedTrainStep:
         self.static_batch = {k: v.clone() for k, v in batch.items()}
         self.captured_lr = get_learning_rate(self.opt)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = self._eager(self.static_batch)
+        self.graph_opt = None
+        if self.grad_sync is None or self.sync_in_graph:
+            with torch.cuda.graph(self.graph):
+                self.static_out = self._eager(self.static_batch)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.static_out = self._fwd_bwd(self.static_batch)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self.opt.step()
 
     def __call__(self, batch):
         self.calls += 1
@@ -182,4 +201,7 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 self.static_batch[k].copy_(v, non_blocking=True)
         self.graph.replay()
+        if self.graph_opt is not None:
+            self.grad_sync.sync()
+            self.graph_opt.replay()
         return self.static_out

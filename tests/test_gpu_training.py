@@ -229,10 +229,11 @@ def test_graphed_step_with_rccl_allreduce_world1(dev):
         system = system.to(dev)
         (opt,), _ = system.configure_optimizers()
         sync = GradSync(system.models, force=True)
-        stepper = GraphedTrainStep(system, opt, grad_sync=sync, warmup=2)
         batch = {"rays": O.make_rays(1, 256, "blender").to(dev), "rgbs": torch.rand(256, 3, device=dev)}
-        ls = [stepper(batch)["loss"].item() for _ in range(8)]
-        assert stepper.graph is not None
-        assert all(torch.isfinite(torch.tensor(ls))) and min(ls[-3:]) < ls[0], ls
+        for in_graph in (False, True):          # [fwd+bwd graph] -> eager all-reduce -> [optimizer graph]  |  one graph
+            stepper = GraphedTrainStep(system, opt, grad_sync=sync, warmup=2, sync_in_graph=in_graph)
+            ls = [stepper(batch)["loss"].item() for _ in range(8)]
+            assert stepper.graph is not None and (stepper.graph_opt is None) == in_graph
+            assert all(torch.isfinite(torch.tensor(ls))) and min(ls[-3:]) < ls[0], (in_graph, ls)
     finally:
         dist.destroy_process_group()
