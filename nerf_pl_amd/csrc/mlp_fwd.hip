@@ -22,6 +22,9 @@
 #ifndef NERFHIP_FAST_SINCOS
 #define NERFHIP_FAST_SINCOS 1   // bf16 kernels only; the fp32 (parity) kernels always use sincosf
 #endif
+#ifndef NERFHIP_EXP
+#define NERFHIP_EXP 0
+#endif
 #ifndef NERFHIP_PF2
 #define NERFHIP_PF2 2      // prefetch depth of the 2-waves-per-SIMD (256-register) bf16 kernels
 #endif
@@ -105,6 +108,13 @@ struct WeightStream {
     }
     // Called by every wave right before the first piece of chunk c is read.
     __device__ __forceinline__ void boundary(int c) {
+#if NERFHIP_EXP == 1          // timing experiment only (results invalid): barriers kept, no refill DMAs after the prologue
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+#elif NERFHIP_EXP == 2        // timing experiment only: neither barriers nor refills (pure MFMA + LDS reads + epilogues)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return;
+#endif
         // (1) my DMAs for chunk c have landed (chunk c+1's may stay in flight), my LDS reads of chunk c-1
         // have returned; (2) barrier: same holds for every wave => chunk c is readable and the slot of
         // chunk c-1 is free; (3) refill that slot with chunk c+2.
@@ -231,7 +241,7 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, SAVE>& st, con
     unsigned gw[4] = {0u, 0u, 0u, 0u};
     static_for<0, N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int t = i / NKS, ks = i % NKS;
+        constexpr int t = frag_tile(i, NT, NKS), ks = frag_slab(i, NT, NKS);
         f32x16& c = acc[t & 1];
         if constexpr (ks == 0) {
             // bias -> accumulator init.  Row of reg r: 32t + (r&3) + 8(r>>2) + 4h  => one f32x4 per (t, r>>2)

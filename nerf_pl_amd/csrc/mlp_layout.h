@@ -85,6 +85,22 @@ NH_HD constexpr int chunks_upto_layer(int Lend, int prec) {   // chunks needed t
     return (layer_start(Lend, prec) + kChunkPieces - 1) / kChunkPieces;
 }
 
+// ---- fragment order inside a layer ------------------------------------------------------------------------
+// Default: output-tile-major, fragment i = (tile i / nks, slab i % nks).  NERFHIP_TILE_PAIRS=1 instead alternates
+// the MFMAs between the two accumulators of a tile pair — (tile 2P + (r & 1), slab r >> 1), P = i / (2 nks),
+// r = i % (2 nks) — so that no MFMA depends on the one issued right before it.  Measured (1024x192, same box):
+// inference forward 188 vs 194 us, but the activation-saving forward 390 vs 347 us (both tiles' epilogues and stores
+// land together: 30 spilled VGPRs), so it stays off.  Pack kernel and MLP kernels share these two functions.
+#ifndef NERFHIP_TILE_PAIRS
+#define NERFHIP_TILE_PAIRS 0
+#endif
+NH_HD constexpr int frag_tile(int i, int nt, int nks) {
+    return (NERFHIP_TILE_PAIRS && nt % 2 == 0) ? 2 * (i / (2 * nks)) + ((i % (2 * nks)) & 1) : i / nks;
+}
+NH_HD constexpr int frag_slab(int i, int nt, int nks) {
+    return (NERFHIP_TILE_PAIRS && nt % 2 == 0) ? (i % (2 * nks)) >> 1 : i % nks;
+}
+
 // ---- input-slot maps --------------------------------------------------------------------------
 // Encoding channel (reference order, nerf.py:33-38: [x, sin f0 x, cos f0 x, sin f1 x, ...]) held by
 // slot (ks,h,j) of an encoding with F frequencies spread over `slabs` slabs; -1 = zero padding.

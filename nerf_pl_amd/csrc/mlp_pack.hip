@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void mlp_pack_kernel(ParamTable P, uint8_t* __r
         } else {
             const int f = (rel - 1) / ppf(PREC), sub = (rel - 1) % ppf(PREC);
             const int nks = ly.enc_slabs + ly.chain_slabs;
-            const int t = f / nks, ks = f % nks;                   // output-tile-major (mlp_fwd.hip run_layer)
+            const int t = frag_tile(f, ly.nt, nks), ks = frag_slab(f, ly.nt, nks);   // fragment order of mlp_fwd.hip run_layer
             const int row = 32 * t + m;
             const float* W = P.w[ly.param];
             const int ldw = kParamIn[ly.param];
