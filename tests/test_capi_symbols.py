@@ -71,3 +71,32 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dp, f)
+
+
+def test_install_registers_reference_module_names():
+    """nerf_pl_amd.install() makes the reference's imports (train.py:10-11, eval.py:9-10, rendering.py:2) resolve here."""
+    import importlib
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("models", "models.nerf", "models.rendering", "torchsearchsorted")}
+    try:
+        import nerf_pl_amd
+        nerf_pl_amd.install()
+        nerf = importlib.import_module("models.nerf")
+        rendering = importlib.import_module("models.rendering")
+        tss = importlib.import_module("torchsearchsorted")
+        from nerf_pl_amd.models import nerf as ours_nerf, rendering as ours_r
+        assert nerf.Embedding is ours_nerf.Embedding and nerf.NeRF is ours_nerf.NeRF
+        assert rendering.render_rays is ours_r.render_rays and rendering.__all__ == ['render_rays']
+        assert callable(tss.searchsorted)
+        # constructor surface and state_dict keys of the reference (nerf.py:42-81)
+        m = nerf.NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4])
+        keys = list(m.state_dict().keys())
+        assert keys[:2] == ["xyz_encoding_1.0.weight", "xyz_encoding_1.0.bias"] and "rgb.0.bias" in keys and len(keys) == 24
+        e = nerf.Embedding(3, 10)
+        assert e.out_channels == 63 and len(e.freq_bands) == 10 and e.funcs[0] is __import__("torch").sin
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
