@@ -1,0 +1,36 @@
+"""Dense sigma-grid query for mesh / volume export (reference extract_color_mesh.py:113-140 and
+extract_mesh.ipynb): sigma on an N x N x N lattice.
+
+The reference materialises the lattice (N^3 x 3), zero directions (N^3 x 3), both embeddings (N^3 x 90) and runs the
+FULL NeRF forward in 32768-point chunks (512 iterations at N = 256) only to keep column 3.  Here every (iy, ix) lattice
+row is handed to the fused MLP kernel as a "ray" with origin (x, y, 0), direction (0, 0, 1) and depths z[0..N-1] — the
+kernel forms o + d*z = (x, y, z) exactly in registers, encodes it and runs the sigma-only network (no direction branch):
+HBM traffic is 4 B in + 4 B out per lattice point."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+@torch.no_grad()
+def sigma_grid(model, N, x_range, y_range, z_range, rows_per_launch=1 << 16, clamp=True):
+    """sigma (N, N, N) float32 on the device, indexed [iy, ix, iz] exactly like the reference's
+    `np.maximum(rgbsigma[:, -1], 0).reshape(N, N, N)` built from `np.meshgrid(x, y, z)` (extract_color_mesh.py:118-140).
+    `clamp=False` returns the raw density."""
+    dev = next(model.parameters()).device
+    # np.linspace in float64, then the float32 cast of torch.FloatTensor(...): extract_color_mesh.py:118-122
+    xs, ys, zs = (torch.from_numpy(np.linspace(lo, hi, N).astype(np.float32)).to(dev) for lo, hi in (x_range, y_range, z_range))
+    iy, ix = torch.meshgrid(torch.arange(N, device=dev), torch.arange(N, device=dev), indexing="ij")
+    rows = torch.zeros(N * N, 8, device=dev, dtype=torch.float32)
+    rows[:, 0] = xs[ix.reshape(-1)]
+    rows[:, 1] = ys[iy.reshape(-1)]
+    rows[:, 5] = 1.0                                   # d = (0, 0, 1): point = (x + 0*z, y + 0*z, 0 + 1*z) exactly
+    packed = model.packed_weights()
+    out = torch.empty(N * N, N, device=dev, dtype=torch.float32)
+    for r0 in range(0, N * N, rows_per_launch):
+        r1 = min(N * N, r0 + rows_per_launch)
+        zv = zs[None, :].expand(r1 - r0, N).contiguous()
+        out[r0:r1] = ops.mlp_fwd_rays(rows[r0:r1], zv, packed, True, model.mlp_dtype)
+    if clamp:
+        out.clamp_(min=0)                              # np.maximum(sigma, 0): extract_color_mesh.py:139
+    return out.view(N, N, N)

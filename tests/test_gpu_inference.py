@@ -83,3 +83,26 @@ def test_empty_and_single_ray_batches(dev):
         got = render_rays(ms, emb, rays.to(dev), 64, False, 0, 0, 64, 32768, True)
     for k, v in ref.items():
         assert torch.allclose(got[k].cpu(), v, rtol=1e-4, atol=1e-4), k
+
+
+def test_sigma_grid_matches_reference_lattice_order(dev):
+    """N4: sigma_grid == the reference's dense query (extract_color_mesh.py:113-140): same lattice (np.meshgrid 'xy'
+    order => [iy, ix, iz]), same values as the oracle MLP on the embedded lattice points, clamped at 0."""
+    import numpy as np
+    from nerf_pl_amd.grid import sigma_grid
+    p = O.make_params(51, 6.0, 0.3)
+    (m,), _ = build_models([p], dev, "fp32")
+    N = 9
+    xr, yr, zr = (-1.2, 1.2), (-1.0, 1.3), (-0.7, 1.1)
+    got = sigma_grid(m, N, xr, yr, zr).cpu()
+    x, y, z = (np.linspace(lo, hi, N) for lo, hi in (xr, yr, zr))
+    xyz = torch.FloatTensor(np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3))
+    ref = O.mlp_forward(p, O.posenc(xyz, 10), sigma_only=True)[:, 0].clamp(min=0).reshape(N, N, N)
+    assert got.shape == (N, N, N)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5), (got - ref).abs().max().item()
+    # chunked launches == single launch (ragged last chunk), bf16 finite and close
+    assert torch.equal(sigma_grid(m, N, xr, yr, zr, rows_per_launch=7).cpu(), got)
+    m.mlp_dtype = "bf16"
+    gb = sigma_grid(m, N, xr, yr, zr, clamp=False).cpu()
+    raw = O.mlp_forward(p, O.posenc(xyz, 10), sigma_only=True)[:, 0].reshape(N, N, N)
+    assert (gb - raw).abs().max().item() <= 3e-2 * max(1.0, raw.abs().max().item())
