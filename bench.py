@@ -50,6 +50,39 @@ def parse():
     return ap.parse_args()
 
 
+# ---- seeded synthetic inputs (BASELINE.json: no dataset / checkpoint offline).  Self-contained on purpose: the only
+# part of this file that touches the CPU checker under its test-infrastructure directory is cpu_baseline(). ----
+PARAM_SHAPES = [("xyz_encoding_%d.0" % (i + 1), 256, 63 if i == 0 else (319 if i == 4 else 256)) for i in range(8)] + \
+               [("xyz_encoding_final", 256, 256), ("dir_encoding.0", 128, 283), ("sigma", 1, 256), ("rgb.0", 3, 128)]
+
+
+def synth_params(seed, sigma_gain=1.0, sigma_bias=0.0):
+    """nn.Linear's default U(-1/sqrt(fan_in), 1/sqrt(fan_in)) from numpy PCG64 (identical on every rank and box);
+    the density head is rescaled so that opacity is non-trivial (a trained-like field)."""
+    import math
+
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, fo, fi in PARAM_SHAPES:
+        b = 1.0 / math.sqrt(fi)
+        p[name + ".weight"] = torch.from_numpy(rng.uniform(-b, b, size=(fo, fi)).astype(np.float32))
+        p[name + ".bias"] = torch.from_numpy(rng.uniform(-b, b, size=(fo,)).astype(np.float32))
+    p["sigma.weight"] = p["sigma.weight"] * sigma_gain
+    p["sigma.bias"] = p["sigma.bias"] * sigma_gain + sigma_bias
+    return p
+
+
+def synth_rays(seed, n):
+    """Blender-style rays (n,8): origins (0,0,4)+0.1N, unit directions aimed near the scene centre, near 2, far 6
+    (blender.py:34-35)."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(n, 3, generator=g)
+    d = 0.8 * torch.randn(n, 3, generator=g) - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return torch.cat([o, d, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0)], 1).float().contiguous()
+
+
 def cpu_baseline(B, S, N, seconds, train):
     """The pinned CPU oracle (torch-CPU restatement of the reference's render_rays, kind='port') timed
     on this node's host cores on the same workload shape; bounded to ~`seconds` of CPU work."""
@@ -124,7 +157,6 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    from oracle import nerf_oracle as O       # only for seeded synthetic inputs + cpu_baseline
     from nerf_pl_amd import ops
     from nerf_pl_amd.models import rendering
     from nerf_pl_amd.parallel import GradSync
@@ -136,15 +168,15 @@ def main():
     system = NeRFSystem(hp)
     # random-init weights of the named architecture (identical on every rank = DDP replicas), density head
     # scaled so that opacity is non-trivial
-    system.nerf_coarse.load_state_dict(O.make_params(100, 4.0, 0.2))
-    system.nerf_fine.load_state_dict(O.make_params(101, 4.0, 0.2))
+    system.nerf_coarse.load_state_dict(synth_params(100, 4.0, 0.2))
+    system.nerf_fine.load_state_dict(synth_params(101, 4.0, 0.2))
     for m in system.models:
         m.mlp_dtype = a.dtype
     system = system.to(dev)
     models, emb = system.models, system.embeddings
     (opt,), _ = system.configure_optimizers()
     grad_sync = GradSync(models) if world > 1 else None
-    rays = O.make_rays(1234 + rank, B, "blender").to(dev)     # each rank draws its own batch
+    rays = synth_rays(1234 + rank, B).to(dev)                 # each rank draws its own batch
     rgbs = torch.rand(B, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
     batch = {"rays": rays, "rgbs": rgbs}
     torch.manual_seed(rank)
@@ -185,7 +217,7 @@ def main():
     if a.mode == "eval":
         from nerf_pl_amd.inference import GraphRenderer
         from nerf_pl_amd.parallel import render_sharded
-        eval_state["rays"] = O.make_rays(77, a.image_rays, "blender").to(dev)
+        eval_state["rays"] = synth_rays(77, a.image_rays).to(dev)
         eval_state["gr"] = GraphRenderer(models, emb, S, N, False, True)
 
     def eval_step():
