@@ -19,6 +19,9 @@
 #ifndef NERFHIP_TILE_SCHED_BARRIER
 #define NERFHIP_TILE_SCHED_BARRIER 0
 #endif
+#ifndef NERFHIP_STORE_AUX
+#define NERFHIP_STORE_AUX 2     // cache-policy bits of the activation stores: 2 = nt (written once, read by another kernel: -7 %)
+#endif
 #ifndef NERFHIP_FAST_SINCOS
 #define NERFHIP_FAST_SINCOS 1   // bf16 kernels only; the fp32 (parity) kernels always use sincosf
 #endif
@@ -184,7 +187,7 @@ __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, uint
         const u32x4* src = reinterpret_cast<const u32x4*>(&slabs[i]);
 #pragma unroll
         for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(src[q], rs, voff + (unsigned)(i * 64 * sizeof(Slab)) + 16 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(src[q], rs, voff + (unsigned)(i * 64 * sizeof(Slab)) + 16 * q, 0, NERFHIP_STORE_AUX);
             st.pending += 1;
         }
     }
