@@ -237,3 +237,26 @@ def test_graphed_step_with_rccl_allreduce_world1(dev):
             assert all(torch.isfinite(torch.tensor(ls))) and min(ls[-3:]) < ls[0], (in_graph, ls)
     finally:
         dist.destroy_process_group()
+
+
+def test_graphed_step_recaptures_on_lr_change(dev):
+    """A scheduler step changes the learning rate (a captured kernel argument): the next call must re-capture."""
+    from argparse import Namespace
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32, loss_type="mse",
+                   lr=5e-4, weight_decay=0, decay_step=[1], decay_gamma=0.5, white_back=True)
+    system = NeRFSystem(hp)
+    for m in system.models:
+        m.mlp_dtype = "bf16"
+    system = system.to(dev)
+    (opt,), (sched,) = system.configure_optimizers()
+    stepper = GraphedTrainStep(system, opt, warmup=1)
+    batch = {"rays": O.make_rays(1, 128, "blender").to(dev), "rgbs": torch.rand(128, 3, device=dev)}
+    for _ in range(4):
+        stepper(batch)
+    g0, w0 = stepper.graph, system.nerf_fine.sigma.weight.detach().clone()
+    assert g0 is not None and stepper.captured_lr == 5e-4
+    sched.step()                                            # epoch boundary: lr 5e-4 -> 2.5e-4 (MultiStepLR, README.md:192)
+    stepper(batch)
+    assert stepper.graph is not g0 and stepper.captured_lr == 2.5e-4
+    assert not torch.equal(system.nerf_fine.sigma.weight.detach(), w0)
