@@ -160,12 +160,24 @@ class GraphedTrainStep:
         self.static_batch = None
         self.static_out = None
         self.captured_lr = None
+        # Eager warm-up steps and the capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream
+        # they were created on, and a node created on the default stream while a later backward is being captured on
+        # another stream is undefined behaviour (observed: silently missing parameter updates, or a segfault).
+        self.stream = torch.cuda.Stream()
+
+    @staticmethod
+    def _detached(out):
+        """The caller gets values, never the autograd graph (a kept-alive loss keeps the previous iteration's
+        AccumulateGrad nodes alive across the capture)."""
+        def d(v):
+            return v.detach() if torch.is_tensor(v) else ({k: d(x) for k, x in v.items()} if isinstance(v, dict) else v)
+        return d(out)
 
     def _fwd_bwd(self, batch):
         out = self.system.training_step(batch, self.calls)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
-        return out
+        return self._detached(out)
 
     def _eager(self, batch):
         out = self._fwd_bwd(batch)
@@ -174,28 +186,36 @@ class GraphedTrainStep:
         self.opt.step()
         return out
 
+    def _on_side_stream(self, fn, *args):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            out = fn(*args)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return out
+
     def _capture(self, batch):
         self.static_batch = {k: v.clone() for k, v in batch.items()}
         self.captured_lr = get_learning_rate(self.opt)
+        self.static_out = None
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
+        torch.cuda.synchronize()
         if self.grad_sync is None or self.sync_in_graph:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.stream):
                 self.static_out = self._eager(self.static_batch)
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.stream):
                 self.static_out = self._fwd_bwd(self.static_batch)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), stream=self.stream):
                 self.opt.step()
 
     def __call__(self, batch):
         self.calls += 1
         if self.calls <= self.warmup:
-            return self._eager(batch)
+            return self._on_side_stream(self._eager, batch)
         if (self.graph is None or get_learning_rate(self.opt) != self.captured_lr
                 or any(batch[k].shape != self.static_batch[k].shape for k in batch)):
-            torch.cuda.synchronize()
             self._capture(batch)
         else:
             for k, v in batch.items():

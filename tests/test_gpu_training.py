@@ -224,6 +224,8 @@ def test_graphed_step_with_rccl_allreduce_world1(dev):
         hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32,
                        loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True)
         system = NeRFSystem(hp)
+        system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
         for m in system.models:
             m.mlp_dtype = "bf16"
         system = system.to(dev)
@@ -246,6 +248,8 @@ def test_graphed_step_recaptures_on_lr_change(dev):
     hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32, loss_type="mse",
                    lr=5e-4, weight_decay=0, decay_step=[1], decay_gamma=0.5, white_back=True)
     system = NeRFSystem(hp)
+    system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))      # seeded, non-dead density (see test_rays.py)
+    system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
     for m in system.models:
         m.mlp_dtype = "bf16"
     system = system.to(dev)

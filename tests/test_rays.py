@@ -101,6 +101,10 @@ def test_train_from_ray_store_end_to_end(dev):
     hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32, loss_type="mse",
                    lr=5e-4, weight_decay=0, decay_step=[10 ** 6], decay_gamma=0.5, white_back=True)
     system = NeRFSystem(hp)
+    # seeded init with a positive density bias: an unseeded default init can start with relu(sigma) == 0 on every
+    # sample (white image, exactly zero gradients) — the classic dead-density start, which never trains
+    system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+    system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
     for m in system.models:
         m.mlp_dtype = "bf16"
     system = system.to(dev)
