@@ -60,7 +60,9 @@ template <int PREC, bool SAVE> struct KCfg {
     static constexpr int WPS = (PREC == NERFHIP_BF16 && (!SAVE || NERFHIP_SAVE8)) ? 2 : 1;
     // A-fragment software prefetch depth (bf16): LDS reads issued this many MFMAs ahead of their use, so the
     // ~100-cycle ds_read latency is not exposed once per 32-cycle MFMA
-    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : ((SAVE && !NERFHIP_SAVE8) ? 8 : NERFHIP_PF2);
+    // (measured at 1024x192: inference forward 197 us with depth 2 vs 204 with depth 1; the 8-wave SAVE variant the
+    //  other way round, 238 vs 257 us — its registers are better spent elsewhere)
+    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : (SAVE ? (NERFHIP_SAVE8 ? 1 : 8) : NERFHIP_PF2);
 };
 
 __device__ __forceinline__ void make_slab(bf16x8& s, const float (&v)[8]) {
