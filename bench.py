@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
 FLOP_PER_POINT_BWD = 2302208       # dX chain 557,696 MAC (no dX into the encodings) + dW 593,408 MAC
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
 def parse():
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16_f8", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "render", "eval"])
     ap.add_argument("--image-rays", type=int, default=640000, help="--mode eval: rays per image (800x800), sharded over ranks")
     ap.add_argument("--rays", type=int, default=1024)

@@ -34,6 +34,10 @@ extern "C" {
 /* MLP arithmetic type (`dtype` arguments). */
 #define NERFHIP_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32 (parity configuration)      */
 #define NERFHIP_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (roofline config)    */
+#define NERFHIP_BF16_F8 2 /* as NERFHIP_BF16 (forward, dX chain: bf16 MFMA); the tensors saved for the weight-gradient
+                           * GEMM (activations X, dY) are stored as block-scaled OCP e4m3 (one e8m0 scale per 32 points x
+                           * 32 features) and consumed by v_mfma_scale_f32_32x32x64_f8f6f4: half the backward's HBM bytes.
+                           * Inference entry points treat it as NERFHIP_BF16.                                          */
 
 typedef void* nerfhip_stream_t;
 
@@ -72,6 +76,13 @@ int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weig
                        const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K, float eps,
                        nerfhip_stream_t stream);
 
+/* Same, additionally exporting what the fused kernel computed on the way (either may be NULL): cdf_out (B,M+1) = the
+ * cdf of rendering.py:31-33 and inds_out (B,K) int64 = searchsorted(cdf, u, side='right') of rendering.py:42 — the
+ * bit-exact contract of the path, checkable against the indices recorded at the reference's own call site.          */
+int nerfhip_sample_pdf_ex(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
+                          const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K, float eps,
+                          float* cdf_out, int64_t* inds_out, nerfhip_stream_t stream);
+
 /* ---- a10. fine-pass depth assembly  (models/rendering.py:223-229) -----------------------
  * z_mid = midpoints(z_coarse); z_new = sample_pdf(z_mid, w_coarse[:,1:-1], N_i, u);
  * z_fine = sort(cat(z_coarse, z_new)).  One launch, one wave per ray.
@@ -79,6 +90,11 @@ int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weig
 int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
                    float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
                    nerfhip_stream_t stream);
+
+/* Same with the optional exports of nerfhip_sample_pdf_ex: cdf_out (B,S_c-1), inds_out (B,N_i) int64.               */
+int nerfhip_fine_z_ex(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride, float* z_fine,
+                      float* z_new, int64_t B, int S_c, int N_i, float eps, float* cdf_out, int64_t* inds_out,
+                      nerfhip_stream_t stream);
 
 /* ---- a7. alpha compositing  (models/rendering.py:143-172) -------------------------------
  * raw: (B,S,4)=[r g b sigma] when raw_ch==4, or (B,S) sigma only when raw_ch==1 (weights_only).
@@ -148,6 +164,15 @@ int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void*
  * d loss / d rgb = 2 (rgb - target) / n.  One launch, deterministic reduction order.                        */
 int nerfhip_mse_psnr(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, float* out3,
                      float* g_coarse, float* g_fine, nerfhip_stream_t stream);
+
+/* ---- N2. Adam on flat parameter storage  (utils/__init__.py:10-30 -> torch.optim.Adam(lr, eps=1e-8, weight_decay)) ----
+ * One launch over `n_tensors` (<= 8) flat fp32 tensors: params/grads/exp_avg/exp_avg_sq are HOST arrays of DEVICE
+ * pointers, numel_host their element counts.  `state` is a 2-float DEVICE buffer {step count, arrival ticket},
+ * zero-initialised by the caller; the kernel uses t = state[0] + 1 for the bias corrections and advances state[0]
+ * itself (device-resident step => hipGraph replays keep counting).  Non-amsgrad, L2 weight decay (g += wd * p).      */
+int nerfhip_adam_step(float* const* params_host, const float* const* grads_host, float* const* exp_avg_host,
+                      float* const* exp_avg_sq_host, const int64_t* numel_host, int n_tensors, float* state, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, nerfhip_stream_t stream);
 
 /* ---- N1. ray generation  (datasets/ray_utils.py:5-94; consumers blender.py:37-69, llff.py:236-253) --------
  * get_ray_directions: dirs (H,W,3) = ((i-W/2)/focal, -(j-H/2)/focal, -1), i = column, j = row.

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERFHIP_LIB_PATH") or os.path.join(_PKG, "libnerfhip.so")   # override: A/B kernel builds
 
-F32, BF16 = 0, 1
+F32, BF16, BF16_F8 = 0, 1, 2
 
 _c_void_p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -30,6 +30,10 @@ SIGNATURES = {
     "nerfhip_searchsorted_left": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
     "nerfhip_sample_pdf": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _int, _int, _f32,
                            _c_void_p],
+    "nerfhip_sample_pdf_ex": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _int, _int, _f32,
+                              _c_void_p, _c_void_p, _c_void_p],
+    "nerfhip_fine_z_ex": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _int, _int, _f32,
+                          _c_void_p, _c_void_p, _c_void_p],
     "nerfhip_fine_z": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _int, _int, _f32,
                        _c_void_p],
     "nerfhip_composite_fwd": [_c_void_p, _int, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _c_void_p,
@@ -52,6 +56,8 @@ SIGNATURES = {
     "nerfhip_gen_rays": [_c_void_p, _c_void_p, _i64, _i64, _int, _int, ctypes.c_double, _f32, _f32, _int, _f32, _c_void_p,
                          _c_void_p],
     "nerfhip_mse_psnr": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "nerfhip_adam_step": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                          ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64), _int, _c_void_p, _f32, _f32, _f32, _f32, _f32, _c_void_p],
     "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
 }
@@ -93,8 +99,38 @@ def check(code, what):
 
 
 def stream_ptr():
-    """Raw hipStream_t of torch's current stream (kernels launch there: DDP overlap, graph capture)."""
+    """Raw hipStream_t of torch's current stream on the CURRENT device (kernels launch there: DDP overlap, graph
+    capture).  Every operator runs under `device_guard`, which makes the tensors' device the current one first."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_tensor(args):
+    for a in args:
+        if torch.is_tensor(a) and a.is_cuda:
+            return a
+        if isinstance(a, (list, tuple)):
+            t = _first_cuda_tensor(a)
+            if t is not None:
+                return t
+    return None
+
+
+def device_guard(fn):
+    """Run `fn` with the device of its first CUDA tensor argument as the current device (what ATen's ops do
+    implicitly): the HIP launch and `stream_ptr()` then refer to the GPU that owns the buffers, also when the
+    caller's current device is a different one."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        t = _first_cuda_tensor(args)
+        if t is None:
+            t = _first_cuda_tensor(tuple(kw.values()))
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kw)
+    return wrapped
 
 
 def ptr(t):
@@ -105,6 +141,7 @@ def ptr(t):
 
 
 def require_gpu(*tensors):
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -112,3 +149,10 @@ def require_gpu(*tensors):
             raise NerfHipError("nerf_pl_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % t.device)
         if t.dtype != torch.float32:
             raise NerfHipError("expected float32 tensor, got %s" % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise NerfHipError("tensors of one call live on different GPUs (%s vs %s)" % (dev, t.device))
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise NerfHipError("launch on %s while the current device is cuda:%d (operator missing its device_guard)"
+                           % (dev, torch.cuda.current_device()))

@@ -6,10 +6,16 @@
 No torch headers, no hipify, no cmake: each csrc/*.hip is compiled to an object with
 `hipcc --offload-arch=gfx950` (in parallel) and linked into nerf_pl_amd/libnerfhip.so, which
 exports the plain-C ABI declared in include/nerfhip.h.  hipcc cross-compiles without a GPU.
+
+Objects are rebuilt individually: an object's stamp is the hash of its source, of the headers it
+(transitively) includes and of its flags.  `mlp_fwd_variant.hip` is compiled once per kernel
+instantiation (-DNH_PREC/-DNH_MODE/-DNH_VARIANT): the 12 fully unrolled forward kernels take ~12
+minutes in one translation unit and ~3 when built side by side.
 """
 import concurrent.futures
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -21,6 +27,11 @@ OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libnerfhip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+EXTRA = [f for f in os.environ.get("NERFHIP_EXTRA_FLAGS", "").split() if f]     # A/B kernel builds (-DNERFHIP_...=)
+
+# (source, object suffix, extra -D flags): sources compiled more than once
+MULTI = {"mlp_fwd_variant.hip": [("_p%dm%dv%d" % (p, m, v), ["-DNH_PREC=%d" % p, "-DNH_MODE=%d" % m, "-DNH_VARIANT=%d" % v])
+                                 for p in (0, 1) for m in (0, 1) for v in (0, 1, 2, 3) if not (v == 3 and p == 0)]}
 
 
 def _hipcc():
@@ -30,48 +41,86 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
 
 
-def _sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+def _jobs():
+    """[(source path, object path, flags)]"""
+    out = []
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith(".hip"):
+            continue
+        src = os.path.join(CSRC, f)
+        for suffix, defs in MULTI.get(f, [("", [])]):
+            out.append((src, os.path.join(OBJ, f[:-4] + suffix + ".o"), FLAGS + EXTRA + defs))
+    return out
 
 
-def _deps_digest():
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _closure(path, seen):
+    """The file and every quoted include below it (relative to the including file)."""
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return
+    seen.add(path)
+    with open(path) as fh:
+        text = fh.read()
+    for inc in _INC.findall(text):
+        _closure(os.path.join(os.path.dirname(path), inc), seen)
+
+
+def _digest(src, flags):
+    files = set()
+    _closure(src, files)
     h = hashlib.sha256()
-    for d in (CSRC, os.path.join(ROOT, "include")):
-        for f in sorted(os.listdir(d)):
-            if f.endswith((".h", ".hip")):
-                h.update(f.encode())
-                with open(os.path.join(d, f), "rb") as fh:
-                    h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(flags).encode())
     return h.hexdigest()
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+def _compile(job):
+    src, obj, flags = job
+    cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    with open(obj + ".stamp", "w") as f:
+        f.write(_digest(src, flags))
     return obj
 
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    stamp = os.path.join(OBJ, "digest.txt")
-    digest = _deps_digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+    jobs = _jobs()
+    todo = []
+    for job in jobs:
+        src, obj, flags = job
+        stamp = obj + ".stamp"
+        if force or not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == _digest(src, flags)):
+            todo.append(job)
+    objs = [j[1] for j in jobs]
+    link_stamp = os.path.join(OBJ, "link.stamp")
+    link_key = hashlib.sha256("\n".join(open(o + ".stamp").read() if os.path.exists(o + ".stamp") else "?" for o in objs).encode()).hexdigest()
+    if not todo and os.path.exists(LIB) and os.path.exists(link_stamp) and open(link_stamp).read() == link_key:
         return LIB
-    srcs = _sources()
     if verbose:
-        print("[nerf_pl_amd.build] hipcc %s: %d sources" % (ARCH, len(srcs)), flush=True)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
+        print("[nerf_pl_amd.build] hipcc %s: %d of %d objects to compile" % (ARCH, len(todo), len(jobs)), flush=True)
+    # the long forward-kernel objects first, so they overlap everything else
+    todo.sort(key=lambda j: 0 if "mlp_fwd_variant" in j[0] else 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 4, 16, len(todo) or 1))) as ex:
+        list(ex.map(_compile, todo))
+    for o in os.listdir(OBJ):                          # objects of sources that no longer exist must not be linked
+        if o.endswith(".o") and os.path.join(OBJ, o) not in objs:
+            os.remove(os.path.join(OBJ, o))
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))
-    with open(stamp, "w") as f:
-        f.write(digest)
+    link_key = hashlib.sha256("\n".join(open(o + ".stamp").read() for o in objs).encode()).hexdigest()
+    with open(link_stamp, "w") as f:
+        f.write(link_key)
     if verbose:
         print("[nerf_pl_amd.build] wrote", LIB, flush=True)
     return LIB

@@ -14,6 +14,7 @@
 //     HBM-bound by construction: 2*256*256 FLOP per 2*256*2 B = 128 FLOP/B.
 #include "common.h"
 #include "mlp_layout.h"
+#include "f8_store.h"
 
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2  // cache-policy bits of the dY stores: 2 = nt (-7 %; whole training step 1.65 -> 1.51 ms)
@@ -51,6 +52,13 @@ __device__ __forceinline__ void mk_slab(f32x8& s, const float (&v)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = v[j];
 }
+__device__ __forceinline__ float slab_absmax8(const bf16x8& s) {
+    float m = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)s[j]));
+    return m;
+}
+__device__ __forceinline__ float slab_absmax8(const f32x8& s) { return 0.0f; }   // (fp8 storage is bf16-only; keeps templates uniform)
 __device__ __forceinline__ float slab_get(const bf16x8& s, int j) { return (float)s[j]; }
 __device__ __forceinline__ float slab_get(const f32x8& s, int j) { return s[j]; }
 
@@ -216,34 +224,51 @@ __device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_
 // acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(pre-act), read as ONE 16-B
 // gate word per lane per layer (bit 8*ks+j, written by the forward's SAVE variant; mask_piece < 0 = no gate),
 // store as dY section, keep as next B operand.
-template <int PREC, bool MASK, int NT, typename Slab>
+// F8: the section is stored as e4m3 slab pairs (f8_store.h); `sc`/`sc0` = the scale-table section being assembled and the
+// index of this section's first pair in it; `dy_tile` = base of the tile's dY block.
+template <int PREC, bool MASK, bool F8, int NT, typename Slab>
 __device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t acts,
-                                             int mask_piece, __amdgpu_buffer_rsrc_t dys, int dy_sec, Slab* out, int lane) {
+                                             int gate_off, int mask_piece, __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile,
+                                             int dy_sec, Slab* out, int lane, F8Scales* sc, int sc0) {
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
-        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u,
-                                                      (unsigned)(act_mask_off(PREC) + mask_piece * kPieceBytes), 0);
+        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
+    float mx = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 2 * NT; ++ks) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gv = acc[ks >> 1][8 * (ks & 1) + j];
-            const int idx = 8 * ks + j;            // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd.hip to_slabs)
+            const int idx = 8 * ks + j;            // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd_kernel.h run_layer)
             const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)gates[idx >> 5], 31 - (idx & 31), 1);   // 0 | ~0
             v[j] = MASK ? __uint_as_float(__float_as_uint(gv) & m) : gv;
+            if (F8) mx = fmaxf(mx, fabsf(v[j]));
         }
         mk_slab(out[ks], v);
-        store_slab(st, dys, dy_sec + ks, out[ks], lane);
+        if constexpr (F8) {
+            if constexpr (PREC == NERFHIP_BF16) {
+                if (ks & 1) {
+                    sc->set(sc0 + (ks >> 1), save_pair_f8(st.pending, dy_tile, (dy_sec + ks) / 2, out[ks - 1], out[ks], mx, lane));
+                    mx = 0.0f;
+                }
+            }
+        } else {
+            store_slab(st, dys, dy_sec + ks, out[ks], lane);
+        }
     }
 }
 
-template <int PREC>
+template <int PREC, bool F8>
 __global__ __launch_bounds__(BwdTraits<PREC>::NW * 64, BwdTraits<PREC>::WPS)
 void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ out, int64_t n,
                           const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
                           uint8_t* __restrict__ dys_base) {
+    static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
     using Slab = typename BwdTraits<PREC>::Slab;
+    constexpr int kActTile = F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC);
+    constexpr int kGateOff = F8 ? f8_act_gate_off() : act_mask_off(PREC);
+    constexpr int kDyTile = F8 ? f8_dy_tile_bytes() : kDySlabs * 64 * (int)sizeof(Slab);
     constexpr int NW = BwdTraits<PREC>::NW;
     __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
     const int lane = threadIdx.x & 63;
@@ -259,9 +284,11 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);               // padded points contribute nothing
 
     __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(acts_base) + (size_t)tile * act_tile_bytes(PREC), 0, act_tile_bytes(PREC), 0x00020000);
-    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(
-        dys_base + (size_t)tile * kDySlabs * 64 * sizeof(Slab), 0, (int)(kDySlabs * 64 * sizeof(Slab)), 0x00020000);
+        const_cast<uint8_t*>(acts_base) + (size_t)tile * kActTile, 0, kActTile, 0x00020000);
+    uint8_t* dy_tile = dys_base + (size_t)tile * kDyTile;
+    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(dy_tile, 0, kDyTile, 0x00020000);
+    F8Scales sc;
+    sc.clear();
 
     BwdStream<PREC> st;
     st.gsrc = packed_bwd + lane * 16;
@@ -288,30 +315,45 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
         for (int j = 0; j < 8; ++j) v[j] = (h == 0 && j == 0) ? g.w : 0.0f;
         mk_slab(g_sig, v);
     }
-    store_slab(st, dys, kDyRgb, g_rgb, lane);
-    store_slab(st, dys, kDyRgb + 1, zero_slab, lane);
-    store_slab(st, dys, kDySigma, g_sig, lane);
-    store_slab(st, dys, kDySigma + 1, zero_slab, lane);
+    if constexpr (F8) {
+        if constexpr (PREC == NERFHIP_BF16) {
+            // scale-table bytes 0..7: rgb, sigma, -, -, dir pairs 1..4 (mlp_layout.h: f8_dy_scale_pos)
+            sc.set(0, save_pair_f8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, slab_absmax8(g_rgb), lane));
+            sc.set(1, save_pair_f8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, slab_absmax8(g_sig), lane));
+        }
+    } else {
+        store_slab(st, dys, kDyRgb, g_rgb, lane);
+        store_slab(st, dys, kDyRgb + 1, zero_slab, lane);
+        store_slab(st, dys, kDySigma, g_sig, lane);
+        store_slab(st, dys, kDySigma + 1, zero_slab, lane);
+    }
 
     // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)
     Slab gd[8];
     {
         f32x16 a4[4];
         run_bwd_layer<PREC, 0, 4, 1>(st, smem_lane, &g_rgb, a4);
-        finish_layer<PREC, true>(st, a4, acts, kMaskPieceT, dys, kDyDir, gd, lane);
+        finish_layer<PREC, true, F8>(st, a4, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir, gd, lane, &sc, 4);
+        if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), 0, sc, lane);
     }
     // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)
     f32x16 acc[8];
     Slab gs[17];
     run_bwd_layer<PREC, 1, 8, 8>(st, smem_lane, gd, acc);
-    finish_layer<PREC, false>(st, acc, acts, 0, dys, kDyFeat, gs, lane);
+    sc.clear();
+    finish_layer<PREC, false, F8>(st, acc, acts, kGateOff, 0, dys, dy_tile, kDyFeat, gs, lane, &sc, 0);
+    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(kDyFeat / 2), sc, lane);
     gs[16] = g_sig;
     // final^T + sigma^T : g_h8 ; mask with h8
     run_bwd_layer<PREC, 2, 8, 17>(st, smem_lane, gs, acc);
-    finish_layer<PREC, true>(st, acc, acts, mask_piece_h(8), dys, dy_h(8), gs, lane);
+    sc.clear();
+    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8), gs, lane, &sc, 0);
+    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(dy_h(8) / 2), sc, lane);
 #define NH_BWD(L)                                                                     \
     run_bwd_layer<PREC, L, 8, 16>(st, smem_lane, gs, acc);                             \
-    finish_layer<PREC, true>(st, acc, acts, mask_piece_h(10 - L), dys, dy_h(10 - L), gs, lane);
+    sc.clear();                                                                        \
+    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), gs, lane, &sc, 0); \
+    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(dy_h(10 - L) / 2), sc, lane);
     NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
 #undef NH_BWD
 }
@@ -502,6 +544,186 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restric
     }
 }
 
+// ================================================================================================
+// Phase B, fp8 storage (NERFHIP_BF16_F8): dW = dY^T X on v_mfma_scale_f32_32x32x64_f8f6f4
+// ================================================================================================
+// Same decomposition as mlp_bwd_dw_kernel (workgroup = (layer job, point split), wave w = 32 dY features x all X tiles,
+// fp32 accumulators in registers), but the operands are the e4m3 slab-pair pieces of mlp_layout.h ("fp8 storage"): one
+// 1 KiB piece = 32 points x 32 features, i.e. HALF the bytes per point of the bf16 kernel, and one MFMA consumes K = 64
+// points = two wave tiles per iteration.
+//   operand fragment of v_mfma_scale_f32_32x32x64_f8f6f4 (measured, tools/probes/probe_fp8.hip): lane (row m = l & 31,
+//   H = l >> 5) holds 32 bytes; bytes 0..15 belong to K block 0, bytes 16..31 to K block 1 (for both lane halves); the
+//   scale operand of lanes 0..31 scales block 0 of row m, that of lanes 32..63 block 1.
+//   => block 0 = tile T0, block 1 = tile T1 of the iteration; lane half H supplies points 16H .. 16H+15 of each.
+//   ds_read_b64_tr_b8 (measured): within a 16-lane group, result lane c (column c & 7, row parity c >> 3) byte b = byte
+//   (c & 7) of the 8-byte chunk addressed by source lane 2b + (c >> 3).  Source lane r therefore points at the chunk of
+//   (point 8g + (r >> 1), half r & 1) and the group's 16 result lanes become the 16 features (h = c >> 3, j = c & 7) of one
+//   slab with 8 consecutive points in their bytes.
+// LDS image of a piece: 16-byte unit u = 16 g + 8 h + (n & 7) <- global unit (lane) 32 h + n, n = 8 g + (n & 7): the 32
+// lanes of one ds_read pass (2 slabs x 8 points x 2 halves) cover one aligned 256-byte block => conflict free.
+struct DwF8Job {
+    int dy_pair0, dy_pairs, dy_pos0;               // pieces / scale-table index of the dY section
+    int x1_pair0, x1_pairs, x1_pos0;
+    int x2_pair0, x2_pairs, x2_pos0;
+};
+
+__device__ __forceinline__ void glds4b(const void* gsrc, unsigned lds_dst) {      // 4 bytes per lane, global -> LDS
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+#ifndef NERFHIP_DWF8_DEPTH
+#define NERFHIP_DWF8_DEPTH 4
+#endif
+
+__global__ __launch_bounds__(512, 2)
+void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restrict__ acts_base,
+                          const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
+    constexpr int DEPTH = NERFHIP_DWF8_DEPTH;
+    constexpr int MAXP = 36;                                   // pieces per stage: 2 tiles x (8 dY + 10 X) pairs
+    constexpr int LPW = 5;                                     // piece DMAs per wave per stage (8 x 5 >= 36)
+    constexpr int STAGE_BYTES = MAXP * kPieceBytes;
+    constexpr int SCALE_BYTES = 256;                           // per wave per stage: [tile][16 dwords]
+    __shared__ __attribute__((aligned(1024))) char ring[DEPTH * STAGE_BYTES + DEPTH * 8 * SCALE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int jid = 0;
+#pragma unroll
+    for (int j = 1; j < kNumDwJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
+    const int nsplit = jobs.nsplit[jid], split = (int)blockIdx.x - jobs.soff[jid];
+    const DwJob jb = jobs.job[jid];
+    const int dyp = jb.dy_slabs / 2, x1p = jb.x1_slabs / 2, x2p = jb.x2_slabs / 2;
+    const int n_ot = dyp, n_xt = x1p + x2p;
+    const int np = dyp + n_xt;                                 // pieces per tile
+    const int dy_pair0 = jb.dy_off / 2, x1_pair0 = jb.x1_off / 2, x2_pair0 = jb.x2_off / 2;
+    // tile PAIRS per split (K = 64 points per MFMA); ntiles is a multiple of 8
+    const int64_t npairs = ntiles / 2;
+    const int64_t per = (npairs + nsplit - 1) / nsplit;
+    const int64_t p_first = (int64_t)split * per;
+    const int64_t my_pairs = (p_first >= npairs) ? 0 : ((npairs - p_first < per) ? npairs - p_first : per);
+    const unsigned lds_base = (unsigned)(uintptr_t)ring;
+    const unsigned lds_scales = lds_base + (unsigned)(DEPTH * STAGE_BYTES);
+
+    // DMA source unit of LDS unit `lane` (see the header comment): global lane 32 h + 8 g + (n & 7)
+    const int dma_unit = ((lane >> 3) & 1) * 32 + 8 * (lane >> 4) + (lane & 7);
+    // scale DMA: lane i < 32 -> (tile i >> 4, slot i & 15): slot 0 = this wave's dY pair, slot 1 + x = X pair x
+    const int s_tile = (lane >> 4) & 1, s_slot = lane & 15;
+    int s_from_dy, s_pos;
+    {
+        const int xq = (s_slot >= 1 && s_slot - 1 < n_xt) ? s_slot - 1 : 0;
+        const int xpos = xq < x1p ? f8_x_scale_pos(x1_pair0 + xq) : f8_x_scale_pos(x2_pair0 + xq - x1p);
+        s_from_dy = (s_slot == 0) ? 1 : 0;
+        s_pos = s_from_dy ? f8_dy_scale_pos(dy_pair0 + (wave < n_ot ? wave : 0)) : xpos;
+    }
+    auto issue_stage = [&](int64_t it) {
+        int64_t P = p_first + (it < my_pairs ? it : my_pairs - 1);                   // past the end: re-fetch the last pair
+        if (P >= npairs) P = npairs - 1;
+        const unsigned slot = lds_base + (unsigned)((it % DEPTH) * STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            int pi = wave + 8 * i;
+            if (pi >= 2 * np) pi = 2 * np - 1;                                       // duplicate DMA of the last piece
+            const int tl = pi >= np ? 1 : 0, pp = pi - tl * np;
+            const int64_t T = 2 * P + tl;
+            const uint8_t* src;
+            if (pp < dyp) src = dys_base + (size_t)T * f8_dy_tile_bytes() + (size_t)(dy_pair0 + pp) * kPieceBytes;
+            else if (pp < dyp + x1p) src = acts_base + (size_t)T * f8_act_tile_bytes() + (size_t)(x1_pair0 + pp - dyp) * kPieceBytes;
+            else src = acts_base + (size_t)T * f8_act_tile_bytes() + (size_t)(x2_pair0 + pp - dyp - x1p) * kPieceBytes;
+            glds16b_nt(src + dma_unit * 16, slot + (unsigned)(pi * kPieceBytes));
+        }
+        {
+            const int64_t T = 2 * P + s_tile;
+            const uint8_t* src = s_from_dy ? dys_base + (size_t)T * f8_dy_tile_bytes() + f8_dy_scale_off()
+                                           : acts_base + (size_t)T * f8_act_tile_bytes() + f8_act_scale_off();
+            glds4b(src + 4 * s_pos, lds_scales + (unsigned)(((it % DEPTH) * 8 + wave) * SCALE_BYTES));
+        }
+    };
+
+    f32x16 acc[kDwMaxXTiles];
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+#pragma unroll
+    for (int x = 0; x < kDwMaxXTiles; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s) issue_stage(s);
+
+    // per-lane read geometry: H = lane >> 5 (points 16H..16H+15 of each tile), s = slab of the pair, r = source row
+    const int H = lane >> 5, sl = (lane >> 4) & 1, r = lane & 15;
+    const int rd_off = ((2 * H) * 16 + (r & 1) * 8 + (r >> 1)) * 16 + sl * 8;        // read q: + (q & 1) * 256, tile (q >> 1): + np KiB
+    const int tile1 = np * kPieceBytes;
+    i32x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = 0x38383838;                                 // e4m3 1.0
+
+    for (int64_t it = 0; it < my_pairs; ++it) {
+        // stage `it` landed (DEPTH-2 younger stages of LPW + 1 DMAs may still fly), everyone done with stage it-1
+        if (DEPTH == 4)      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_stage(it + DEPTH - 1);
+        if (wave < n_ot) {
+            const char* st_base = ring + (it % DEPTH) * STAGE_BYTES + rd_off;
+            const char* sc_base = ring + DEPTH * STAGE_BYTES + ((it % DEPTH) * 8 + wave) * SCALE_BYTES + H * 64;
+            auto load_frag = [&](int piece) {
+                i32x8 f;
+                const char* pb = st_base + piece * kPieceBytes;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                        (__attribute__((address_space(3))) i32x2*)(pb + (q >> 1) * tile1 + (q & 1) * 256));
+                    f[2 * q] = v[0];
+                    f[2 * q + 1] = v[1];
+                }
+                return f;
+            };
+            const i32x8 a = load_frag(wave);
+            const int sa = *reinterpret_cast<const int*>(sc_base);
+            accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, 0, 0, 0, sa, 0, 127);
+#pragma unroll
+            for (int x = 0; x < kDwMaxXTiles; ++x) {
+                if (x < n_xt) {
+                    const i32x8 b = load_frag(dyp + x);
+                    const int sb = *reinterpret_cast<const int*>(sc_base + 4 * (1 + x));
+                    acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[x], 0, 0, 0, sa, 0, sb);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
+
+    if (wave < n_ot) {
+        float* slb = slabs + (size_t)blockIdx.x * kDwSlabFloats;
+#pragma unroll
+        for (int x = 0; x < kDwMaxXTiles; ++x) {
+            if (x < n_xt) {
+                float* dst = slb + ((size_t)(wave * kDwMaxXTiles + x) * 64 + lane) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
+            }
+        }
+        // bias partials: every column of accb equals sum_p dY[p][row]; lanes 0 and 32 hold column 0 (rows 4H + (r&3) + 8(r>>2))
+        if ((lane & 31) == 0) {
+            float* bdst = slb + 8 * kDwMaxXTiles * 64 * 16 + wave * 64;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
+        }
+    }
+}
+
+
 struct GradTable {
     float* w[12];
     float* b[12];
@@ -510,6 +732,9 @@ struct GradTable {
 // sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients.
 // One 256-thread block per (job, 32x32 tile): thread = one float4 (rows o..o+3 of one column) of the 1024-float
 // tile, summed over the job's splits with independent 16-B loads.
+// F8: operand rows/columns arrive in the order ds_read_b64_tr_b8 delivers them (m -> slab m >> 4, half (m >> 3) & 1, slot m & 7)
+// instead of natural feature order, and the bias partials hold one value per row.
+template <bool F8>
 __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, const float* __restrict__ slabs, GradTable G,
                                                               int accumulate) {
     const int jid = blockIdx.y;
@@ -526,9 +751,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
             float s = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) {
                 const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
-                s += sl[m] + sl[m + 32];
+                s += F8 ? sl[m] : sl[m] + sl[m + 32];
             }
-            const int o = 32 * ot + m;
+            const int o = F8 ? 32 * ot + chain_feature(m >> 4, f8_row_h(m & 15), f8_row_j(m & 15)) : 32 * ot + m;
             if (o < n_out) G.b[jb.param][o] = accumulate ? G.b[jb.param][o] + s : s;
         }
         return;
@@ -545,18 +770,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
     }
     const int lane = e4 >> 2, rq = e4 & 3;
     const int h = lane >> 5, ncol = lane & 31;
-    const int o0 = 32 * ot + 8 * rq + 4 * h;           // rows o0 .. o0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
+    const int m0 = 8 * rq + 4 * h;                     // operand rows m0 .. m0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
+    // natural order: row m = feature 32 ot + m.  F8: m -> feature chain_feature(m >> 4, (m >> 3) & 1, m & 7) of the tile
+    const int o0 = F8 ? 32 * ot + chain_feature(m0 >> 4, f8_row_h(m0 & 15), f8_row_j(m0 & 15)) : 32 * ot + m0;   // k adds to (m & 3)
     const int xi = 32 * xt + ncol;
     int xs = xi >> 4;
     const int i = xi & 15;
+    const int sh = F8 ? f8_row_h(i) : slab_nat_h(i), sj = F8 ? f8_row_j(i) : slab_nat_j(i);     // slot (h, j) inside slab xs
     int enc, col0;
     if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
     else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
     int col;
-    if (enc == 0) col = col0 + 16 * xs + i;
+    if (enc == 0) col = col0 + chain_feature(xs, sh, sj);
     else {
-        const int ch = (enc == 1) ? xyz_slot_channel(xs, slab_nat_h(i), slab_nat_j(i))
-                                  : dir_slot_channel(xs, slab_nat_h(i), slab_nat_j(i));
+        const int ch = (enc == 1) ? xyz_slot_channel(xs, sh, sj) : dir_slot_channel(xs, sh, sj);
         col = ch < 0 ? -1 : col0 + ch;
     }
     if (col >= 0 && col < ldw) {
@@ -577,15 +804,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static inline bool valid_dtype(int dtype) { return dtype == NERFHIP_F32 || dtype == NERFHIP_BF16 || dtype == NERFHIP_BF16_F8; }
+static inline int compute_prec(int dtype) { return dtype == NERFHIP_F32 ? NERFHIP_F32 : NERFHIP_BF16; }
+
 extern "C" size_t nerfhip_mlp_packed_bwd_bytes(int dtype) {
-    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return 0;
+    if (!valid_dtype(dtype)) return 0;
+    dtype = compute_prec(dtype);
     return (size_t)nerfhip::mlp::bwd_padded_pieces(dtype) * nerfhip::mlp::kPieceBytes;
 }
 
 extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
                                             nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(weights_host && packed_bwd);
-    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return NERFHIP_E_UNSUPPORTED;
+    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
+    dtype = compute_prec(dtype);
     if (((uintptr_t)packed_bwd) & 15) return NERFHIP_E_ALIGN;
     nerfhip::WTable P;
     for (int i = 0; i < 12; ++i) {
@@ -601,19 +833,20 @@ extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, vo
 }
 
 static int64_t act_tiles(int64_t n_points, int dtype) {
-    const int64_t ppw = 32 * (dtype == NERFHIP_BF16 ? 8 : 4);
+    const int64_t ppw = 32 * (dtype == NERFHIP_F32 ? 4 : 8);
     return (n_points + ppw - 1) / ppw * (ppw / 32);
 }
 
 extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
-    if (n_points < 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    if (n_points < 0 || !valid_dtype(dtype)) return 0;
+    if (dtype == NERFHIP_BF16_F8) return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::f8_dy_tile_bytes();
     return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
 }
 
 // NERFHIP_DW_WGS / 12 splits per job (fewer for few tiles)
 static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
     using namespace nerfhip::mlp;
-    const int64_t tiles = act_tiles(n_points, dtype);
+    const int64_t tiles = act_tiles(n_points, dtype) / (dtype == NERFHIP_BF16_F8 ? 2 : 1);   // f8: units of work are tile PAIRS
     int off = 0;
     for (int j = 0; j < kNumDwJobs; ++j) {
         int64_t ns = NERFHIP_DW_WGS / kNumDwJobs;
@@ -631,7 +864,7 @@ static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
 }
 
 extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {      // total (job, split) workgroups / partial slabs
-    if (n_points <= 0 || (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16)) return 0;
+    if (n_points <= 0 || !valid_dtype(dtype)) return 0;
     return dw_plan(n_points, dtype, nullptr);
 }
 
@@ -643,7 +876,7 @@ extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, 
                                const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
                                float* const* grad_b_host, int accumulate, int dtype, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n >= 0);
-    if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return NERFHIP_E_UNSUPPORTED;
+    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
     NERFHIP_CHECK_ARG(grad_w_host && grad_b_host);
     nerfhip::GradTable G;
     for (int i = 0; i < 12; ++i) {
@@ -659,18 +892,26 @@ extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, 
     const int64_t tiles = act_tiles(n, dtype);
     nerfhip::DwJobTable jt;
     const int nwg = dw_plan(n, dtype, &jt);
+    const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs);
+    if (dtype == NERFHIP_BF16_F8) {
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
+                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, tiles, (const uint8_t*)acts,
+                           (const uint8_t*)dys, (float*)dw_workspace);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
+        return nerfhip_launch_status();
+    }
     if (dtype == NERFHIP_BF16) {
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16>, dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, out,
-                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
+                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
         hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, tiles,
                            (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     } else {
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, out,
-                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out,
+                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
         hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, tiles,
                            (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     }
-    hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel, dim3(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs),
-                       dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
+    hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
     return nerfhip_launch_status();
 }

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void mlp_pack_kernel(ParamTable P, uint8_t* __r
 }  // namespace nerfhip
 
 extern "C" size_t nerfhip_mlp_packed_bytes(int dtype) {
+    if (dtype == NERFHIP_BF16_F8) dtype = NERFHIP_BF16;          // same weight image: only the saved tensors differ
     if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return 0;
     return (size_t)nerfhip::mlp::padded_pieces(dtype) * nerfhip::mlp::kPieceBytes;
 }
@@ -71,6 +72,7 @@ extern "C" size_t nerfhip_mlp_packed_bytes(int dtype) {
 extern "C" int nerfhip_mlp_pack_weights(const float* const* weights_host, const float* const* biases_host,
                                         void* packed, int dtype, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(weights_host && biases_host && packed);
+    if (dtype == NERFHIP_BF16_F8) dtype = NERFHIP_BF16;
     if (dtype != NERFHIP_F32 && dtype != NERFHIP_BF16) return NERFHIP_E_UNSUPPORTED;
     if (((uintptr_t)packed) & 15) return NERFHIP_E_ALIGN;
     nerfhip::ParamTable P;

@@ -111,8 +111,10 @@ __device__ __forceinline__ void build_cdf_wave(WLoad wload, int M, float eps, fl
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float invert_cdf(const float* cdf_s, const float* bins_s, int M, float u, float eps) {
+__device__ __forceinline__ float invert_cdf(const float* cdf_s, const float* bins_s, int M, float u, float eps,
+                                            int* ind_out = nullptr) {
     const int ind = upper_bound(cdf_s, M + 1, u);   // searchsorted(cdf,u,'right')   :42
+    if (ind_out) *ind_out = ind;
     const int below = max(ind - 1, 0);              // :43
     const int above = min(ind, M);                  // :44
     const float cb = cdf_s[below], ca = cdf_s[above];
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
                                                           const float* __restrict__ weights, int64_t w_stride,
                                                           const float* __restrict__ u, int64_t u_stride,
                                                           float* __restrict__ samples, int64_t B, int M, int K,
-                                                          float eps) {
+                                                          float eps, float* __restrict__ cdf_out,
+                                                          int64_t* __restrict__ inds_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -137,9 +140,13 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     for (int j = lane; j <= M; j += 64) bins_s[j] = bins[r * bins_stride + j];
     const float* wrow = weights + r * w_stride;
     build_cdf_wave([&](int j) { return wrow[j]; }, M, eps, cdf_s, lane);
+    if (cdf_out)
+        for (int j = lane; j <= M; j += 64) cdf_out[r * (M + 1) + j] = cdf_s[j];
     for (int k = lane; k < K; k += 64) {
         const float uk = u ? u[r * u_stride + k] : linspace01(k, K);
-        samples[r * K + k] = invert_cdf(cdf_s, bins_s, M, uk, eps);
+        int ind;
+        samples[r * K + k] = invert_cdf(cdf_s, bins_s, M, uk, eps, &ind);
+        if (inds_out) inds_out[r * K + k] = (int64_t)ind;
     }
 }
 
@@ -155,7 +162,8 @@ __device__ __forceinline__ int fine_z_lds_floats(int S, int N) {
 __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ zc, const float* __restrict__ wc,
                                                       const float* __restrict__ u, int64_t u_stride,
                                                       float* __restrict__ zf, float* __restrict__ znew_out,
-                                                      int64_t B, int S, int N, float eps) {
+                                                      int64_t B, int S, int N, float eps, float* __restrict__ cdf_out,
+                                                      int64_t* __restrict__ inds_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -175,9 +183,13 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
     for (int j = lane; j < S - 1; j += 64) bins_s[j] = nh_mul(0.5f, nh_add(zc_s[j], zc_s[j + 1]));  // :223
     const float* wrow = wc + r * S + 1;         // weights_coarse[:, 1:-1]          :225
     build_cdf_wave([&](int j) { return wrow[j]; }, M, eps, cdf_s, lane);
+    if (cdf_out)
+        for (int j = lane; j <= M; j += 64) cdf_out[r * (M + 1) + j] = cdf_s[j];
     for (int k = lane; k < N; k += 64) {
         const float uk = u ? u[r * u_stride + k] : linspace01(k, N);
-        const float v = invert_cdf(cdf_s, bins_s, M, uk, eps);
+        int ind;
+        const float v = invert_cdf(cdf_s, bins_s, M, uk, eps, &ind);
+        if (inds_out) inds_out[r * N + k] = (int64_t)ind;
         zn_s[k] = v;
         if (znew_out) znew_out[r * N + k] = v;
         const int ub = upper_bound(zc_s, S, v);  // #coarse <= v
@@ -253,21 +265,27 @@ extern "C" int nerfhip_searchsorted_left(const float* a, const float* v, int64_t
     return searchsorted_impl(a, v, idx, B, M, K, false, stream);
 }
 
-extern "C" int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
-                                  const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K,
-                                  float eps, nerfhip_stream_t stream) {
+extern "C" int nerfhip_sample_pdf_ex(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
+                                     const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K,
+                                     float eps, float* cdf_out, int64_t* inds_out, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(B >= 0 && M >= 1 && K >= 0 && M <= 2040);
     if (B == 0 || K == 0) return 0;
     NERFHIP_CHECK_ARG(bins && weights && samples);
     hipLaunchKernelGGL(nerfhip::sample_pdf_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256),
                        (size_t)4 * 2 * (M + 1) * sizeof(float), (hipStream_t)stream, bins, bins_stride, weights,
-                       w_stride, u, u_stride, samples, B, M, K, eps);
+                       w_stride, u, u_stride, samples, B, M, K, eps, cdf_out, inds_out);
     return nerfhip_launch_status();
 }
+extern "C" int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
+                                  const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K,
+                                  float eps, nerfhip_stream_t stream) {
+    return nerfhip_sample_pdf_ex(bins, bins_stride, weights, w_stride, u, u_stride, samples, B, M, K, eps, nullptr, nullptr,
+                                 stream);
+}
 
-extern "C" int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
-                              float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
-                              nerfhip_stream_t stream) {
+extern "C" int nerfhip_fine_z_ex(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
+                                 float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps, float* cdf_out,
+                                 int64_t* inds_out, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(B >= 0 && S_c >= 3 && N_i >= 1);
     const int S4 = (S_c + 3) & ~3, N4 = (N_i + 3) & ~3;
     const size_t per_wave = (size_t)(3 * S4 + N4 + ((S_c + 1 + 3) & ~3) + N4) * sizeof(float);
@@ -275,6 +293,11 @@ extern "C" int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, cons
     if (B == 0) return 0;
     NERFHIP_CHECK_ARG(z_coarse && w_coarse && z_fine);
     hipLaunchKernelGGL(nerfhip::fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 4 * per_wave,
-                       (hipStream_t)stream, z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps);
+                       (hipStream_t)stream, z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, cdf_out, inds_out);
     return nerfhip_launch_status();
+}
+extern "C" int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
+                              float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
+                              nerfhip_stream_t stream) {
+    return nerfhip_fine_z_ex(z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, nullptr, nullptr, stream);
 }

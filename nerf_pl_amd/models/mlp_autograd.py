@@ -7,7 +7,18 @@ d/d(rays, z) is never needed; d/dx of pre-embedded inputs is not implemented (ra
 import torch
 
 from .. import ops
-from . import mlp_backward
+
+
+def _param_grads(model, out, acts, dtype, g_out):
+    """nerfhip_mlp_bwd (chain + dW + reduce kernels) -> gradients in `flat_params()` order."""
+    packed_bwd = model.packed_weights_bwd(dtype)
+    gw, gb, flat = ops.mlp_bwd(g_out, out, packed_bwd, acts, dtype)
+    model._flat_grad = flat          # contiguous view of this step's gradients (parallel.GradSync / FlatAdam use it)
+    hook = getattr(model, "_grad_ready_hook", None)
+    if hook is not None:             # parallel.GradSync: start this model's all-reduce while autograd keeps going
+        hook(model, flat)
+    need = [p.requires_grad for p in model.flat_params()]
+    return [g if nd else None for g, nd in zip(gw + gb, need)]
 
 
 def _needs_grad(model):
@@ -29,7 +40,7 @@ class _MLPRays(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         (out,) = ctx.saved_tensors
-        grads = mlp_backward.backward_rays(ctx.model, out, ctx.acts, ctx.dtype, g_out)
+        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out)
         ctx.acts = None
         return (None, None, None) + tuple(grads)
 
@@ -52,22 +63,34 @@ class _MLPEmbedded(torch.autograd.Function):
             raise NotImplementedError("nerf_pl_amd: gradient w.r.t. pre-embedded NeRF inputs is not implemented "
                                       "(never needed by the reference: rays carry no grad)")
         (out,) = ctx.saved_tensors
-        grads = mlp_backward.backward_embedded(ctx.model, out, ctx.acts, ctx.dtype, g_out)
+        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out)
         ctx.acts = None
         return (None, None) + tuple(grads)
 
 
 def mlp_rays(model, rays, z, sigma_only):
-    if _needs_grad(model) and not sigma_only:
-        return _MLPRays.apply(model, rays, z, *model.flat_params())
+    if _needs_grad(model):
+        out = _MLPRays.apply(model, rays, z, *model.flat_params())
+        # sigma_only under grad (render_rays(test_time=True) outside no_grad): the reference's sigma-only forward is
+        # differentiable (nerf.py:103-114), so evaluate the full network and keep the density channel; the colour
+        # branch then simply receives zero gradient.
+        return out[..., 3] if sigma_only else out
     return ops.mlp_fwd_rays(rays, z, model.packed_weights(), sigma_only, model.mlp_dtype)
 
 
 def mlp_embedded(model, x, sigma_only):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1]).float()
-    if (_needs_grad(model) or (torch.is_grad_enabled() and x2.requires_grad)) and not sigma_only:
-        out = _MLPEmbedded.apply(model, x2, *model.flat_params())
+    if _needs_grad(model) or (torch.is_grad_enabled() and x2.requires_grad):
+        if sigma_only:
+            # differentiable sigma-only forward (nerf.py:103-114): full network on [xyz | 0 direction channels], density
+            # channel kept; colour-branch parameters get zero gradient
+            if x2.shape[1] != model.in_channels_xyz:
+                raise ValueError("NeRF.forward expects %d input channels, got %d" % (model.in_channels_xyz, x2.shape[1]))
+            x2 = torch.cat([x2, x2.new_zeros(x2.shape[0], model.in_channels_dir)], 1)
+            out = _MLPEmbedded.apply(model, x2, *model.flat_params())[:, 3:4]
+        else:
+            out = _MLPEmbedded.apply(model, x2, *model.flat_params())
     else:
         out = ops.mlp_fwd_embedded(x2, model.packed_weights(), sigma_only, model.mlp_dtype)
     return out.reshape(*lead, out.shape[-1])

@@ -9,15 +9,17 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, NerfHipError, check, ptr, require_gpu, stream_ptr
+from ._lib import BF16, BF16_F8, F32, NerfHipError, check, device_guard, ptr, require_gpu, stream_ptr
 
+# 'bf16_f8': bf16 MFMA forward and dX chain; the tensors saved for the weight-gradient GEMM (activations, dY) are stored
+# as block-scaled e4m3 and consumed by the MX-scaled fp8 MFMA (include/nerfhip.h: NERFHIP_BF16_F8)
 _DTYPES = {"fp32": F32, "f32": F32, "float32": F32, torch.float32: F32, F32: F32,
-           "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16}
+           "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16, "bf16_f8": BF16_F8}
 
 
 def mlp_dtype_code(d):
     if isinstance(d, bool) or d not in _DTYPES:
-        raise ValueError("mlp dtype must be 'fp32' or 'bf16', got %r" % (d,))
+        raise ValueError("mlp dtype must be 'fp32', 'bf16' or 'bf16_f8', got %r" % (d,))
     return _DTYPES[d]
 
 
@@ -49,6 +51,7 @@ class _PosEnc(torch.autograd.Function):
         return gx, None
 
 
+@device_guard
 def posenc(x, n_freqs):
     """Embedding.forward (reference models/nerf.py:21-38), logscale bands. x (n,C) -> (n, C(2F+1))."""
     if x.dim() != 2:
@@ -57,6 +60,7 @@ def posenc(x, n_freqs):
 
 
 # ------------------------------------------------------------------------------- sampling (a5, a8-a10)
+@device_guard
 def sample_coarse_z(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
     """rendering.py:183-204.  rays (B,8) -> z (B,S)."""
     require_gpu(rays, perturb_rand)
@@ -73,6 +77,7 @@ def sample_coarse_z(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=N
     return z
 
 
+@device_guard
 def searchsorted(a, v, out=None, side="left"):
     """Drop-in for torchsearchsorted.searchsorted (reference models/rendering.py:2,42): batched
     row-wise numpy-style searchsorted; a (B,M), v (B,K) float32 -> int64 (B,K)."""
@@ -93,8 +98,10 @@ def searchsorted(a, v, out=None, side="left"):
     return out
 
 
-def sample_pdf_u(bins, weights, n_importance, u=None, eps=1e-5):
-    """sample_pdf with explicit uniforms: u None -> deterministic linspace; (K,) or (B,K) otherwise."""
+@device_guard
+def sample_pdf_u(bins, weights, n_importance, u=None, eps=1e-5, return_cdf_inds=False):
+    """sample_pdf with explicit uniforms: u None -> deterministic linspace; (K,) or (B,K) otherwise.
+    return_cdf_inds: also return the kernel's cdf (B,M+1) and searchsorted indices (B,K) int64 (rendering.py:31-42)."""
     require_gpu(bins, weights, u)
     if bins.stride(-1) != 1:
         bins = bins.contiguous()
@@ -113,14 +120,18 @@ def sample_pdf_u(bins, weights, n_importance, u=None, eps=1e-5):
         elif u.shape != (n_importance,):
             raise ValueError("u must be (N_importance,) or (B, N_importance)")
     samples = torch.empty(B, n_importance, device=bins.device, dtype=torch.float32)
-    check(_lib.load().nerfhip_sample_pdf(ptr(bins), bins.stride(0), ptr(weights), weights.stride(0), ptr(u), u_stride,
-                                         ptr(samples), B, M, n_importance, float(eps), stream_ptr()),
+    cdf = torch.empty(B, M + 1, device=bins.device, dtype=torch.float32) if return_cdf_inds else None
+    inds = torch.empty(B, n_importance, device=bins.device, dtype=torch.int64) if return_cdf_inds else None
+    check(_lib.load().nerfhip_sample_pdf_ex(ptr(bins), bins.stride(0), ptr(weights), weights.stride(0), ptr(u), u_stride,
+                                            ptr(samples), B, M, n_importance, float(eps), ptr(cdf), ptr(inds), stream_ptr()),
           "nerfhip_sample_pdf")
-    return samples
+    return (samples, cdf, inds) if return_cdf_inds else samples
 
 
-def fine_z(z_coarse, w_coarse, n_importance, u=None, eps=1e-5, return_new=False):
-    """rendering.py:223-229 in one launch: z_fine = sort(cat(z_coarse, sample_pdf(z_mid, w[:,1:-1])))."""
+@device_guard
+def fine_z(z_coarse, w_coarse, n_importance, u=None, eps=1e-5, return_new=False, return_cdf_inds=False):
+    """rendering.py:223-229 in one launch: z_fine = sort(cat(z_coarse, sample_pdf(z_mid, w[:,1:-1]))).
+    return_cdf_inds: append the fused kernel's cdf (B,S-1) and searchsorted indices (B,N_i) to the result."""
     require_gpu(z_coarse, w_coarse, u)
     z_coarse, w_coarse = _c(z_coarse), _c(w_coarse)
     B, S = z_coarse.shape
@@ -130,9 +141,14 @@ def fine_z(z_coarse, w_coarse, n_importance, u=None, eps=1e-5, return_new=False)
         u_stride = n_importance if u.dim() == 2 else 0
     zf = torch.empty(B, S + n_importance, device=z_coarse.device, dtype=torch.float32)
     zn = torch.empty(B, n_importance, device=z_coarse.device, dtype=torch.float32) if return_new else None
-    check(_lib.load().nerfhip_fine_z(ptr(z_coarse), ptr(w_coarse), ptr(u), u_stride, ptr(zf), ptr(zn), B, S,
-                                     n_importance, float(eps), stream_ptr()), "nerfhip_fine_z")
-    return (zf, zn) if return_new else zf
+    cdf = torch.empty(B, S - 1, device=z_coarse.device, dtype=torch.float32) if return_cdf_inds else None
+    inds = torch.empty(B, n_importance, device=z_coarse.device, dtype=torch.int64) if return_cdf_inds else None
+    check(_lib.load().nerfhip_fine_z_ex(ptr(z_coarse), ptr(w_coarse), ptr(u), u_stride, ptr(zf), ptr(zn), B, S,
+                                        n_importance, float(eps), ptr(cdf), ptr(inds), stream_ptr()), "nerfhip_fine_z")
+    out = (zf, zn) if return_new else (zf,)
+    if return_cdf_inds:
+        out = out + (cdf, inds)
+    return out if len(out) > 1 else out[0]
 
 
 # ------------------------------------------------------------------------------- compositing (a7)
@@ -179,6 +195,7 @@ class _Composite(torch.autograd.Function):
         return g_raw, None, None, None, None, None
 
 
+@device_guard
 def composite(raw, z, rays, noise=None, noise_std=0.0, white_back=False):
     """Volume-rendering quadrature (rendering.py:143-172).
     raw (B,S,4) -> (weights, opacity, rgb, depth);  raw (B,S) sigma-only -> (weights, opacity)."""
@@ -212,6 +229,7 @@ class _MsePsnr(torch.autograd.Function):
         return g_c * g_loss, (g_f * g_loss if g_f is not None else None), None
 
 
+@device_guard
 def mse_psnr(rgb_coarse, rgb_fine, target):
     """MSELoss.forward (losses.py:9-14) + psnr (metrics.py:4-13) + d loss/d rgb in one launch.
     Returns (loss [differentiable scalar], out3 = [loss, psnr, mse] detached)."""
@@ -230,6 +248,7 @@ def packed_bytes(dtype):
     return int(_lib.load().nerfhip_mlp_packed_bytes(mlp_dtype_code(dtype)))
 
 
+@device_guard
 def pack_weights(weights, biases, dtype, out=None):
     """Repack 12 (weight, bias) fp32 tensors (state_dict order, PARAM_ORDER) into the MFMA A-fragment
     stream of `dtype`.  Returns a uint8 device buffer."""
@@ -275,10 +294,12 @@ def pack_arg_tables(weights, biases):
     return wp, bp
 
 
+@device_guard
 def pack_weights_raw(wp, bp, out, dtype):
     check(_lib.load().nerfhip_mlp_pack_weights(wp, bp, ptr(out), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_mlp_pack_weights")
 
 
+@device_guard
 def pack_weights_bwd_raw(wp, out, dtype):
     check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), mlp_dtype_code(dtype), stream_ptr()),
           "nerfhip_mlp_pack_weights_bwd")
@@ -289,6 +310,7 @@ def alloc_acts(n_points, dtype, device):
     return torch.empty(nbytes, device=device, dtype=torch.uint8)
 
 
+@device_guard
 def mlp_fwd_embedded(x, packed, sigma_only, dtype, save=None):
     require_gpu(x)
     if x.dim() != 2 or x.stride(1) != 1:
@@ -304,6 +326,7 @@ def mlp_fwd_embedded(x, packed, sigma_only, dtype, save=None):
     return out
 
 
+@device_guard
 def mlp_fwd_rays(rays, z, packed, sigma_only, dtype, save=None):
     require_gpu(rays, z)
     rays, z = _c(rays), _c(z)
@@ -315,6 +338,7 @@ def mlp_fwd_rays(rays, z, packed, sigma_only, dtype, save=None):
 
 
 # ------------------------------------------------------------------------------- MLP backward (K2b)
+@device_guard
 def pack_weights_bwd(weights, dtype, out=None):
     """W^T A-fragment stream for the backward chain (12 weights, state_dict order)."""
     code = mlp_dtype_code(dtype)
@@ -328,6 +352,7 @@ def pack_weights_bwd(weights, dtype, out=None):
     return out
 
 
+@device_guard
 def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
     """Gradients of all 24 parameter tensors given dL/d(out).  Returns ([gw0..gw11], [gb0..gb11])."""
     require_gpu(g_out, out)
@@ -342,7 +367,8 @@ def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
     # one flat fp32 buffer for all 24 gradients (595,844 floats): autograd adopts the views as p.grad,
     # so a model's gradients are contiguous => ONE RCCL all-reduce per model, no flatten copies
     sizes = [s[0] * s[1] for s in shapes] + [s[0] for s in shapes]
-    flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+    # n == 0: the C entry point launches nothing, so the gradients of an empty batch must be explicit zeros
+    flat = (torch.zeros if n == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
     views, off = [], 0
     for sz in sizes:
         views.append(flat[off:off + sz])

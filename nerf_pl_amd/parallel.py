@@ -6,8 +6,9 @@ over xGMI on ROCm; "gloo" in the CPU tests).
 * Training is the reference's DDP (train.py:174-175): replicated models, each rank draws its own
   batch, gradients are averaged.  Each model's 24 gradients live in ONE flat fp32 buffer written by
   the dW-reduce kernel (2.38 MB), so a step needs exactly one all-reduce per model — a message that on
-  the 8-GPU xGMI mesh is latency-bound (~10 us of wire time) and is issued for the fine model while
-  the coarse model's backward is still running (autograd runs fine first).
+  the 8-GPU xGMI mesh is latency-bound (~10 us of wire time).  `GradSync` issues the fine model's all-reduce from a
+  grad-ready hook of the fused backward, i.e. while the coarse model's backward is still running (autograd runs the
+  fine model first); see `GradSync._on_grad_ready`.
 """
 import torch
 import torch.distributed as dist
@@ -49,31 +50,81 @@ def render_sharded(render_fn, rays, keys=("rgb_fine", "depth_fine", "opacity_fin
 
 
 class GradSync:
-    """Average gradients across ranks: one all-reduce per model on its flat gradient buffer when the
-    HIP backward produced one, else a flatten/all-reduce/unflatten of the parameter grads."""
+    """Average gradients across ranks (the reference's DDP, train.py:174-175): one all-reduce per model on the flat
+    gradient buffer the dW-reduce kernel wrote (2.38 MB), else a flatten/all-reduce/unflatten of the parameter grads.
 
-    def __init__(self, models, group=None, force=False):
+    Overlap with backward (what DDP's bucket hooks give the reference): `attach()` registers a grad-ready hook on each
+    model; the fused MLP backward calls it the moment the model's flat gradient buffer is complete
+    (models/mlp_autograd.py:_param_grads), and the hook issues that model's all-reduce asynchronously on the
+    communicator's stream.  Autograd runs the fine model's backward first, so its all-reduce travels over xGMI while
+    compositing / importance sampling / the coarse model's backward still execute; `sync()` then waits for whatever
+    was started, launches whatever was not, and divides by the world size."""
+
+    def __init__(self, models, group=None, force=False, overlap=True):
         self.models = list(models)
         self.group = group
         self.force = force          # run the collectives even at world size 1 (tests the RCCL path on one GPU)
+        self.overlap = overlap
+        self.hooks_enabled = True   # GraphedTrainStep switches the hooks off while it captures/replays a graph that
+                                    # must not contain the collective (two-graph mode)
+        self._inflight = {}         # id(model) -> (work, flat)
+        self.started_early = 0      # statistics: all-reduces issued from the hook (tests assert on it)
+        if overlap:
+            self.attach()
 
+    # -- plumbing ---------------------------------------------------------------------------------------------------
+    def active(self):
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+
+    def attach(self):
+        for m in self.models:
+            m._grad_ready_hook = self._on_grad_ready
+
+    def detach(self):
+        for m in self.models:
+            if getattr(m, "_grad_ready_hook", None) == self._on_grad_ready:
+                m._grad_ready_hook = None
+
+    def _avg_op(self):
+        """(reduce op, needs_division): RCCL averages in the collective itself; gloo (CPU tests) has no AVG."""
+        backend = dist.get_backend(self.group)
+        if backend == "nccl" and hasattr(dist.ReduceOp, "AVG"):
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, True
+
+    def _on_grad_ready(self, model, flat):
+        if not (self.hooks_enabled and self.overlap and self.active()):
+            return
+        op, div = self._avg_op()
+        self._inflight[id(model)] = (dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, div)
+        self.started_early += 1
+
+    # -- the step-level call ----------------------------------------------------------------------------------------
     def sync(self):
-        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force):
+        if not self.active():
+            self._inflight.clear()
             return
         world = dist.get_world_size(self.group)
+        op, div = self._avg_op()
         works = []
         for m in self.models:
             flat = getattr(m, "_flat_grad", None)
+            early = self._inflight.pop(id(m), None)
+            if early is not None and flat is not None and early[1].data_ptr() == flat.data_ptr():
+                works.append((early[0], flat, None, early[2]))
+                continue
             params = [p for p in m.parameters() if p.grad is not None]
             if (flat is not None and params and params[0].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
                     and params[-1].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()):
-                works.append((dist.all_reduce(flat, group=self.group, async_op=True), flat, None))
+                works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, None, div))
             elif params:
                 buf = torch.cat([p.grad.reshape(-1) for p in params])
-                works.append((dist.all_reduce(buf, group=self.group, async_op=True), buf, params))
-        for w, buf, params in works:
+                works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf, params, div))
+        self._inflight.clear()
+        for w, buf, params, need_div in works:
             w.wait()
-            buf.div_(world)
+            if need_div:
+                buf.div_(world)
             if params is not None:
                 off = 0
                 for p in params:

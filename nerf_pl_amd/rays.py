@@ -7,17 +7,19 @@ each batch's rays from 8-byte pixel ids (`nerfhip_gen_rays`), so a training batc
 import torch
 
 from . import _lib
-from ._lib import check, ptr, require_gpu, stream_ptr
+from ._lib import check, device_guard, ptr, require_gpu, stream_ptr
 
 
 def get_ray_directions(H, W, focal, device="cuda"):
     """(H, W, 3) camera-space ray directions.  Reference: datasets/ray_utils.py:5-24."""
     dirs = torch.empty(H, W, 3, device=device, dtype=torch.float32)
-    require_gpu(dirs)
-    check(_lib.load().nerfhip_ray_directions(ptr(dirs), int(H), int(W), float(focal), stream_ptr()), "nerfhip_ray_directions")
+    with torch.cuda.device(dirs.device):
+        require_gpu(dirs)
+        check(_lib.load().nerfhip_ray_directions(ptr(dirs), int(H), int(W), float(focal), stream_ptr()), "nerfhip_ray_directions")
     return dirs
 
 
+@device_guard
 def get_rays(directions, c2w):
     """rays_o, rays_d (H*W, 3) in world coordinates.  Reference: datasets/ray_utils.py:27-52."""
     require_gpu(directions)
@@ -32,6 +34,7 @@ def get_rays(directions, c2w):
     return rays_o, rays_d
 
 
+@device_guard
 def get_ndc_rays(H, W, focal, near, rays_o, rays_d):
     """World rays -> NDC rays.  Reference: datasets/ray_utils.py:55-94."""
     require_gpu(rays_o, rays_d)
@@ -43,6 +46,7 @@ def get_ndc_rays(H, W, focal, near, rays_o, rays_d):
     return out_o, out_d
 
 
+@device_guard
 def gen_rays(c2w, H, W, focal, near, far, pixel_ids=None, first_pixel=0, n=None, use_ndc=False, ndc_near_plane=1.0):
     """rays (n, 8) = [o d near far] for global pixel ids (image*H*W + row*W + col) under poses c2w (n_images, 3, 4)."""
     require_gpu(c2w)

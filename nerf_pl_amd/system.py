@@ -71,17 +71,41 @@ class NeRFSystem(_Base):
         return results
 
     def configure_optimizers(self):
-        """Adam(lr, eps=1e-8, weight_decay) over all models + MultiStepLR (utils/__init__.py:10-53)."""
+        """get_optimizer + get_scheduler of the reference (utils/__init__.py:10-53), dispatched on the same hparams
+        (`optimizer`, `momentum`, `weight_decay`, `lr_scheduler`, `num_epochs`, `poly_exp`, `decay_step`, `decay_gamma`).
+        Recipes this package does not implement raise instead of silently training with a different one."""
         hp = self.hp
+        eps = 1e-8
         params = [p for m in self.models for p in m.parameters()]
-        if params[0].is_cuda and getattr(hp, 'flat_optimizer', True):
-            from .optim import FlatAdam           # same Adam math on one flat tensor per model (2 launches, not 48 tensors)
-            self.optimizer = FlatAdam(self.models, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0))
+        name = getattr(hp, 'optimizer', 'adam')
+        wd = getattr(hp, 'weight_decay', 0)
+        if name == 'adam':
+            if params[0].is_cuda and getattr(hp, 'flat_optimizer', True):
+                from .optim import FlatAdam       # same Adam math on one flat tensor per model (HIP kernel, 2 launches)
+                self.optimizer = FlatAdam(self.models, lr=hp.lr, eps=eps, weight_decay=wd)
+            else:
+                self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=eps, weight_decay=wd, fused=params[0].is_cuda)
+        elif name == 'sgd':
+            self.optimizer = torch.optim.SGD(params, lr=hp.lr, momentum=getattr(hp, 'momentum', 0.9), weight_decay=wd)
+        elif name in ('radam', 'ranger'):
+            raise NotImplementedError("optimizer %r (utils/optimizers.py of the reference) is outside the hot path this "
+                                      "package implements; use 'adam' or 'sgd'" % name)
         else:
-            self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=getattr(hp, 'weight_decay', 0),
-                                              fused=params[0].is_cuda)
-        scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(getattr(hp, 'decay_step', [20])),
-                                                         gamma=getattr(hp, 'decay_gamma', 0.1))
+            raise ValueError('optimizer not recognized!')
+
+        sched = getattr(hp, 'lr_scheduler', 'steplr')
+        if sched == 'steplr':
+            scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(getattr(hp, 'decay_step', [20])),
+                                                             gamma=getattr(hp, 'decay_gamma', 0.1))
+        elif sched == 'cosine':
+            scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=hp.num_epochs, eta_min=eps)
+        elif sched == 'poly':
+            n_ep, pexp = hp.num_epochs, getattr(hp, 'poly_exp', 0.9)
+            scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda epoch: (1 - epoch / n_ep) ** pexp)
+        else:
+            raise ValueError('scheduler not recognized!')
+        if getattr(hp, 'warmup_epochs', 0) > 0:
+            raise NotImplementedError("warmup_epochs > 0 (utils/warmup_scheduler.py of the reference) is not implemented")
         return [self.optimizer], [scheduler]
 
     def training_step(self, batch, batch_nb):
@@ -150,7 +174,7 @@ class GraphedTrainStep:
     exercised at world size 1 here).
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
-    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False):
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False, backend=None):
         self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
         self.warmup = warmup
         self.sync_in_graph = sync_in_graph
@@ -160,10 +184,10 @@ class GraphedTrainStep:
         self.static_batch = None
         self.static_out = None
         self.captured_lr = None
-        # Eager warm-up steps and the capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream
-        # they were created on, and a node created on the default stream while a later backward is being captured on
-        # another stream is undefined behaviour (observed: silently missing parameter updates, or a segfault).
-        self.stream = torch.cuda.Stream()
+        # `backend` abstracts the three device facilities the stepper needs (side stream, graph capture, replay) so the
+        # host logic — warm-up, capture, two-graph step with the eager collective in between, re-capture on lr change —
+        # can be exercised by the world-2 gloo CPU test with a recording stand-in (tests/test_distributed_cpu.py).
+        self.backend = backend if backend is not None else _HipGraphBackend()
 
     @staticmethod
     def _detached(out):
@@ -186,34 +210,36 @@ class GraphedTrainStep:
         self.opt.step()
         return out
 
-    def _on_side_stream(self, fn, *args):
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            out = fn(*args)
-        torch.cuda.current_stream().wait_stream(self.stream)
-        return out
+    def _two_graphs(self):
+        return self.grad_sync is not None and not self.sync_in_graph
+
+    def _set_hooks(self, on):
+        if self.grad_sync is not None and hasattr(self.grad_sync, "hooks_enabled"):
+            self.grad_sync.hooks_enabled = on
 
     def _capture(self, batch):
         self.static_batch = {k: v.clone() for k, v in batch.items()}
         self.captured_lr = get_learning_rate(self.opt)
         self.static_out = None
-        self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
-        torch.cuda.synchronize()
-        if self.grad_sync is None or self.sync_in_graph:
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.static_out = self._eager(self.static_batch)
+        if not self._two_graphs():
+            # one graph: forward, backward, [all-reduces issued from the grad-ready hooks, i.e. overlapping the rest of
+            # the backward also on replay], optimizer
+            self.graph, self.static_out = self.backend.capture(lambda: self._eager(self.static_batch))
         else:
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.static_out = self._fwd_bwd(self.static_batch)
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), stream=self.stream):
-                self.opt.step()
+            # two graphs with the collectives issued eagerly in between: the hooks must stay silent, or the fine
+            # model's all-reduce would be captured into the first graph
+            self._set_hooks(False)
+            try:
+                self.graph, self.static_out = self.backend.capture(lambda: self._fwd_bwd(self.static_batch))
+                self.graph_opt, _ = self.backend.capture(self.opt.step, share_pool_with=self.graph)
+            finally:
+                self._set_hooks(True)
 
     def __call__(self, batch):
         self.calls += 1
         if self.calls <= self.warmup:
-            return self._on_side_stream(self._eager, batch)
+            return self.backend.on_side_stream(self._eager, batch)
         if (self.graph is None or get_learning_rate(self.opt) != self.captured_lr
                 or any(batch[k].shape != self.static_batch[k].shape for k in batch)):
             self._capture(batch)
@@ -225,3 +251,29 @@ class GraphedTrainStep:
             self.grad_sync.sync()
             self.graph_opt.replay()
         return self.static_out
+
+
+class _HipGraphBackend:
+    """Side stream + hipGraph capture/replay through torch.cuda.CUDAGraph.
+
+    Eager warm-up steps and the capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream they
+    were created on, and a node created on the default stream while a later backward is being captured on another
+    stream is undefined behaviour (observed: silently missing parameter updates, or a segfault)."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+
+    def on_side_stream(self, fn, *args):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            out = fn(*args)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return out
+
+    def capture(self, fn, share_pool_with=None):
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        kw = {"pool": share_pool_with.pool()} if share_pool_with is not None else {}
+        with torch.cuda.graph(graph, stream=self.stream, **kw):
+            out = fn()
+        return graph, out

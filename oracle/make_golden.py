@@ -213,6 +213,45 @@ def main():
     G["gr_full_f_rgb.0.weight"] = mf.rgb[0].weight.grad.clone()
     G["gr_full_f_xyz_encoding_1.0.bias"] = getattr(mf, "xyz_encoding_1")[0].bias.grad.clone()
 
+    # ---------------------------------------------------------------- 6b. gradients at the other train configurations
+    # gr3: BASELINE configs[2] shape (64 + 128 samples, perturb=1, noise_std=0, white background — the README lego recipe);
+    # gr4: configs[3] shape (LLFF/NDC rays: near 0, far 1, non-unit directions, noise_std=1, black background, 64 + 64).
+    # (fresh generators: nothing above this point may change when cases are added here)
+    for prefix, (kind, B, S_c, N_i, pert, nstd, wb, sg, sb, seed) in {
+            "gr3": ("blender", 32, 64, 128, 1.0, 0.0, True, 6.0, 0.3, 2100),
+            "gr4": ("ndc", 32, 64, 64, 1.0, 1.0, False, 6.0, 0.3, 2200)}.items():
+        pc, pf = O.make_params(seed, sg, sb), O.make_params(seed + 500, sg, sb)
+        rays = O.make_rays(seed, B, kind)
+        rng = O.draw_rng(seed, B, S_c, N_i, pert)
+        tgt = torch.rand(B, 3, generator=torch.Generator().manual_seed(seed))
+        for key in ("perturb_rand", "noise_coarse", "u", "noise_fine"):
+            replay.push("rand" if key in ("perturb_rand", "u") else "randn", rng[key])
+        mc, mf = ref_model(nerf, pc), ref_model(nerf, pf)
+        res = rend.render_rays([mc, mf], emb, rays, S_c, False, pert, nstd, N_i, 1024 * 32, wb)
+        assert not replay.queue
+        loss = torch.nn.functional.mse_loss(res["rgb_coarse"], tgt) + torch.nn.functional.mse_loss(res["rgb_fine"], tgt)
+        loss.backward()
+        G[f"{prefix}_cfg"] = torch.tensor([{"blender": 0, "ndc": 1}[kind], B, S_c, N_i, 0, pert, nstd, int(wb), 0, sg, sb, seed],
+                                          dtype=torch.float64)
+        G[f"{prefix}_target"] = tgt
+        G[f"{prefix}_loss"] = loss.detach()
+        G[f"{prefix}_rgb_fine"] = res["rgb_fine"].detach()
+        for tag, mod in (("c", mc), ("f", mf)):
+            for n, prm in mod.named_parameters():
+                G[f"{prefix}_{tag}_{n}"] = O.grad_digest(prm.grad)
+        G[f"{prefix}_full_c_sigma.weight"] = mc.sigma.weight.grad.clone()
+        G[f"{prefix}_full_f_rgb.0.weight"] = mf.rgb[0].weight.grad.clone()
+        G[f"{prefix}_full_f_xyz_encoding_1.0.bias"] = getattr(mf, "xyz_encoding_1")[0].bias.grad.clone()
+        G[f"{prefix}_full_f_dir_encoding.0.weight"] = mf.dir_encoding[0].weight.grad.clone()
+        # the oracle restatement reproduces these gradients (autograd through nerf_oracle.render_rays)
+        opc = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+        opf = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+        ores = O.render_rays([opc, opf], rays, S_c, False, pert, nstd, N_i, wb, False, rng=rng)
+        O.mse_loss(ores, tgt).backward()
+        for n, prm in mf.named_parameters():
+            scale = prm.grad.abs().max().item() + 1e-12
+            assert (opf[n].grad - prm.grad).abs().max().item() <= 1e-4 * scale, (prefix, n)
+
     # ---------------------------------------------------------------- 7. ray geometry (datasets/ray_utils.py), N1
     ru = ref_shim.load_reference_ray_utils()
     for tag, (H, W, focal, pose_seed) in {"blender": (20, 24, 27.7777, 31), "llff": (19, 25, 21.5, 32)}.items():

@@ -27,7 +27,7 @@ class ReplayRNG:
 
 
 def case_from_golden(golden, name, prefix="rr"):
-    key = f"{prefix}_{name}_cfg" if prefix == "rr" else "gr_cfg"
+    key = f"{prefix}_{name}_cfg" if prefix == "rr" else f"{prefix}_cfg"
     cfg = golden[key].tolist()
     kind = {0: "blender", 1: "ndc"}[int(cfg[0])]
     B, S_c, N_i = int(cfg[1]), int(cfg[2]), int(cfg[3])
@@ -73,3 +73,37 @@ def hip_render(models, embeddings, rays, kw, rng, device):
         rendering.torch = saved
     assert not replay.q
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Procedural "easy" scene for PSNR gates (no dataset offline): a soft-edged ball of smoothly varying colour in front of a
+# white background, rendered in closed form (dense quadrature of the analytic field, fp64) — so the targets come from
+# neither the HIP path nor the oracle.  A NeRF reaches > 25 dB on it within a few hundred 1024-ray steps.
+def analytic_field(x):
+    """x (...,3) -> sigma (...), rgb (...,3)."""
+    r = x.norm(dim=-1)
+    sigma = 40.0 * torch.sigmoid((0.9 - r) * 10.0)
+    rgb = 0.5 + 0.4 * torch.stack([torch.sin(1.5 * x[..., 0]), torch.sin(1.5 * x[..., 1] + 1.0),
+                                   torch.sin(1.5 * x[..., 2] + 2.0)], -1)
+    return sigma, rgb
+
+
+def analytic_scene(n, seed, device, n_quad=384):
+    """n Blender-style rays [o d near=2 far=6] aimed at the ball from a radius-4 sphere + their ground-truth colours."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 4.0
+    tgt = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * (1.3 * torch.rand(n, 1, generator=g))
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    rays = torch.cat([o, d, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0)], 1).float().contiguous().to(device)
+    out = []
+    for i in range(0, n, 65536):
+        r = rays[i:i + 65536].double()
+        t = torch.linspace(2.0, 6.0, n_quad, device=device, dtype=torch.float64)
+        pts = r[:, None, :3] + r[:, None, 3:6] * t[None, :, None]
+        sigma, rgb = analytic_field(pts)
+        delta = (t[1] - t[0]).expand_as(sigma)
+        alpha = 1.0 - torch.exp(-sigma * delta)
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], 1), 1)[:, :-1]
+        w = alpha * T
+        out.append(((w[..., None] * rgb).sum(1) + (1.0 - w.sum(1, keepdim=True))).float())
+    return rays, torch.cat(out, 0)

@@ -34,6 +34,89 @@ class _Tiny(torch.nn.Module):
         self.b = torch.nn.Linear(7, 3)
 
 
+class _RecordingBackend:
+    """Stand-in for system._HipGraphBackend on CPU.  Like a stream capture, `capture` does NOT execute the work (it only
+    records the callable); every `replay` executes it and refreshes the static output holder in place — the same
+    contract (static inputs, static outputs, nothing runs at capture time) without a device."""
+
+    class _G:
+        def __init__(self, fn, holder):
+            self.fn, self.holder, self.replays = fn, holder, 0
+
+        def replay(self):
+            self.replays += 1
+            r = self.fn()
+            if isinstance(r, dict):
+                self.holder.clear()
+                self.holder.update(r)
+
+    def __init__(self):
+        self.captures = 0
+
+    def on_side_stream(self, fn, *args):
+        return fn(*args)
+
+    def capture(self, fn, share_pool_with=None):
+        self.captures += 1
+        holder = {}
+        return self._G(fn, holder), holder
+
+
+class _TinySystem(torch.nn.Module):
+    """training_step contract of NeRFSystem (train.py:103-117) on a toy model whose backward announces its flat gradient
+    buffer exactly like the fused HIP backward does (models/mlp_autograd._param_grads)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.net = _Tiny()
+        self.models = [self.net]
+
+    def training_step(self, batch, nb):
+        y = self.net.b(torch.relu(self.net.a(batch["x"])))
+        return {"loss": ((y - batch["y"]) ** 2).mean()}
+
+
+def _graphed_step_host_logic(rank, world):
+    from nerf_pl_amd.system import GraphedTrainStep
+    g = torch.Generator().manual_seed(100 + rank)           # every rank draws its own batch (weak scaling)
+    batches = [{"x": torch.randn(16, 5, generator=g), "y": torch.randn(16, 3, generator=g)} for _ in range(7)]
+    sysm = _TinySystem()
+    opt = torch.optim.SGD(sysm.parameters(), lr=0.1)
+    sync = parallel.GradSync(sysm.models)
+    be = _RecordingBackend()
+    stepper = GraphedTrainStep(sysm, opt, grad_sync=sync, warmup=2, backend=be)
+    for b in batches[:5]:
+        stepper(b)
+    ok = be.captures == 2 and stepper.graph is not None and stepper.graph_opt is not None      # two graphs
+    ok = ok and stepper.graph.replays == 3 and stepper.graph_opt.replays == 3                    # calls 3,4,5 replayed
+    ok = ok and sync.hooks_enabled
+    for grp in opt.param_groups:                            # scheduler step: lr is a captured argument
+        grp["lr"] = 0.05
+    for b in batches[5:]:
+        stepper(b)
+    ok = ok and be.captures == 4 and stepper.captured_lr == 0.05
+    # replicas stay identical (same init, averaged gradients) and equal a single-process run on the averaged gradient
+    flat = torch.cat([p.detach().reshape(-1) for p in sysm.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    ref = _TinySystem()
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    allb = [[{"x": torch.randn(16, 5, generator=gg), "y": torch.randn(16, 3, generator=gg)} for _ in range(7)] for gg in gens]
+    for i in range(7):
+        if i == 5:
+            for grp in ropt.param_groups:
+                grp["lr"] = 0.05
+        ropt.zero_grad()
+        for r in range(world):
+            (ref.training_step(allb[r][i], i)["loss"] / world).backward()
+        ropt.step()
+    rflat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    return bool(ok and torch.allclose(flat, rflat, rtol=1e-5, atol=1e-6))
+
+
 def _worker(rank, world, port, n_rays, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,7 +149,35 @@ def _worker(rank, world, port, n_rays, q):
         ok_flat = torch.allclose(flat, torch.arange(sum(sizes), dtype=torch.float32) * want)
         # and the parameters' .grad still alias the averaged buffer
         ok_alias = all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in m2.parameters())
-        q.put((rank, ok_render, ok_generic, ok_flat, ok_alias))
+        # --- GradSync, overlap: the fused backward announces a finished flat buffer through the grad-ready hook; the
+        # all-reduce is issued THEN (while "the rest of backward" still runs) and sync() only waits and averages
+        m3 = _Tiny()
+        gs = parallel.GradSync([m3])
+        flat3 = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) + 1.0
+        off = 0
+        for p, sz in zip(m3.parameters(), sizes):
+            p.grad = flat3[off:off + sz].view_as(p)
+            off += sz
+        m3._flat_grad = flat3
+        assert m3._grad_ready_hook is not None
+        m3._grad_ready_hook(m3, flat3)                      # what models/mlp_autograd._param_grads does
+        started = gs.started_early
+        gs.sync()
+        ok_overlap = started == 1 and not gs._inflight and torch.allclose(
+            flat3, torch.arange(sum(sizes), dtype=torch.float32) * want + 1.0)
+        # hooks switched off (two-graph capture): nothing is issued early, sync() does the whole job
+        gs.hooks_enabled = False
+        flat3.copy_(torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1))
+        m3._grad_ready_hook(m3, flat3)
+        ok_overlap = ok_overlap and gs.started_early == 1
+        gs.sync()
+        ok_overlap = ok_overlap and torch.allclose(flat3, torch.arange(sum(sizes), dtype=torch.float32) * want)
+
+        # --- the N>1 training step's host logic (system.GraphedTrainStep): eager warm-up steps, capture of
+        # [forward+backward] and [optimizer] as two graphs with the collective issued eagerly in between, replays,
+        # re-capture on a learning-rate change — with a recording stand-in for the hipGraph backend.
+        ok_step = _graphed_step_host_logic(rank, world)
+        q.put((rank, ok_render, ok_generic, ok_flat, ok_alias, ok_overlap, ok_step))
     finally:
         dist.destroy_process_group()
 

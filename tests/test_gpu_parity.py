@@ -3,7 +3,7 @@ against the pinned CPU oracle on the same seeded inputs.
 
 Tolerances (stated per north_star): integer/index work bit-exact; fp32 path 1e-4 relative
 (rtol=1e-4 with an absolute floor of 1e-4 on O(1) quantities); bf16 MFMA path is not a parity
-configuration (gated on PSNR, see test_gpu_bf16.py) and only sanity-bounded here."""
+configuration (gated on PSNR and gradient direction in tests/test_gpu_bf16.py) and only sanity-bounded here."""
 import numpy as np
 import pytest
 import torch
@@ -38,6 +38,23 @@ def test_posenc_ragged_and_large(dev):
     assert ops.posenc(torch.zeros(0, 3, device=dev), 10).shape == (0, 63)
 
 
+def test_posenc_backward_vs_autograd(dev):
+    """nerfhip_posenc_bwd == autograd through the oracle's Embedding restatement (nerf.py:21-38)."""
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for n, C, F, span in ((1, 3, 10, 2.0), (65, 3, 10, 6.0), (1000, 3, 4, 1.0), (77, 2, 6, 3.0), (5, 3, 0, 1.0)):
+        x = (torch.rand(n, C, generator=g) * 2 - 1) * span
+        go = torch.randn(n, C * (2 * F + 1), generator=g)
+        x0 = x.clone().requires_grad_(True)
+        (O.posenc(x0, F) * go).sum().backward()
+        x1 = x.clone().to(dev).requires_grad_(True)
+        (ops.posenc(x1, F) * go.to(dev)).sum().backward()
+        # d/dx sin(2^k x) = 2^k cos(2^k x): terms up to 2^(F-1) |gout| are summed in a different order
+        scale = x0.grad.abs().max().item()
+        err = (x1.grad.cpu() - x0.grad).abs().max().item()
+        assert err <= 2e-6 * scale + 1e-6, (n, C, F, err, scale)
+
+
 def test_searchsorted_bit_exact(golden, dev):
     from nerf_pl_amd import ops
     for tag, ukey in (("det64", "ss_det64_u"), ("det128", "ss_det128_u"), ("rand", "sp_rand_u")):
@@ -67,19 +84,61 @@ def test_sample_pdf_vs_reference_golden(golden, dev):
     # rounded sum, so: (a) most elements equal the golden value, (b) every element equals the reference
     # algorithm for SOME rounding of the row total within +-2 ulp (oracle.matches_some_total_rounding).
     cb, cw = golden["sp_bins"], golden["sp_w"]
+    report = []
     for n in (64, 128):
         out = sample_pdf(bins, w, n, det=True).cpu()
         close = (out - golden[f"sp_det{n}"]).abs() <= 2e-6
-        assert close.float().mean().item() > 0.97
+        report.append(("det%d" % n, 1.0 - close.float().mean().item()))
+        assert close.float().mean().item() > 0.99            # measured 0.3-0.5 % (knife edges of the +-2 ulp row total)
         assert bool(O.matches_some_total_rounding(out, cb, cw, n).all())
     ur = golden["sp_rand_u"]
     out = ops.sample_pdf_u(bins, w, 128, u=ur.to(dev)).cpu()
-    assert ((out - golden["sp_rand128"]).abs() <= 2e-6).float().mean().item() > 0.97
+    close = (out - golden["sp_rand128"]).abs() <= 2e-6
+    report.append(("rand128", 1.0 - close.float().mean().item()))
+    assert close.float().mean().item() > 0.99
     assert bool(O.matches_some_total_rounding(out, cb, cw, 128, u=ur).all())
+    print("sample_pdf: fraction of samples differing from the reference-minted vectors by > 2e-6:",
+          ", ".join("%s %.4f" % r for r in report))
     # strided weights view (the reference passes weights_coarse[:, 1:-1])
     wpad = torch.rand(40, 64)
     out2 = ops.sample_pdf_u(bins, wpad.to(dev)[:, 1:-1], 64).cpu()
     assert bool(O.matches_some_total_rounding(out2, cb, wpad[:, 1:-1], 64).all())
+
+
+def test_fused_sample_pdf_indices_bit_exact(golden, dev):
+    """The searchsorted indices INSIDE the fused sample_pdf / fine_z kernels (north_star: bit-exact) against the
+    (cdf, u) -> inds triples recorded at the reference's own call site (rendering.py:42).  The kernel's cdf can differ
+    from the reference's in the last bit (correctly rounded row total vs torch.sum's SIMD-order-dependent one): rows
+    whose cdf is bit-equal must give bit-equal indices; for the others the indices must equal numpy's searchsorted of
+    the kernel's OWN cdf.  The fractions are printed, not hidden behind a band."""
+    from nerf_pl_amd import ops
+    bins, w = golden["sp_bins"].to(dev), golden["sp_w"].to(dev)
+    for tag, K, ukey in (("det64", 64, None), ("det128", 128, None), ("rand", 128, "sp_rand_u")):
+        u = None if ukey is None else golden[ukey]
+        _, cdf, inds = ops.sample_pdf_u(bins, w, K, u=None if u is None else u.to(dev), return_cdf_inds=True)
+        cdf, inds = cdf.cpu(), inds.cpu()
+        ref_cdf, ref_inds, ref_u = golden[f"ss_{tag}_cdf"], golden[f"ss_{tag}_inds"], golden[f"ss_{tag}_u" if ukey is None else ukey]
+        assert inds.dtype == torch.int64 and inds.shape == ref_inds.shape and cdf.shape == ref_cdf.shape
+        rows_equal = (cdf == ref_cdf).all(-1)
+        assert int(rows_equal.sum()) >= 8            # (measured: ~half of the rows; the rest differ in the last bit somewhere)
+        assert (cdf - ref_cdf).abs().max().item() <= 2.4e-7     # ... by at most 2 ulp of a value <= 1
+        assert torch.equal(inds[rows_equal], ref_inds[rows_equal])
+        own = np.stack([np.searchsorted(cdf[i].numpy(), ref_u[i].numpy(), side="right") for i in range(cdf.shape[0])])
+        assert np.array_equal(inds.numpy(), own)
+        print("fused sample_pdf %s: cdf rows bit-equal %.3f, cdf max ulp-ish diff %.2e, indices equal to the reference %.5f"
+              % (tag, rows_equal.float().mean().item(), (cdf - ref_cdf).abs().max().item(), (inds == ref_inds).float().mean().item()))
+    # the same export from the fused fine_z kernel agrees with the stand-alone kernel on the same inputs
+    g = torch.Generator().manual_seed(2)
+    rays = O.make_rays(1, 40, "blender")
+    z = O.coarse_z(rays, 64, False, 1.0, torch.rand(40, 64, generator=g))
+    wc = torch.rand(40, 64, generator=g) ** 4
+    uu = torch.rand(40, 128, generator=g)
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    _, cdf_a, inds_a = ops.sample_pdf_u(mid.to(dev), wc[:, 1:-1].to(dev), 128, u=uu.to(dev), return_cdf_inds=True)
+    _, cdf_b, inds_b = ops.fine_z(z.to(dev), wc.to(dev), 128, u=uu.to(dev), return_cdf_inds=True)
+    assert torch.equal(cdf_a, cdf_b) and torch.equal(inds_a, inds_b)
+    own = np.stack([np.searchsorted(cdf_b[i].cpu().numpy(), uu[i].numpy(), side="right") for i in range(40)])
+    assert np.array_equal(inds_b.cpu().numpy(), own)
 
 
 def test_coarse_z_bit_exact(dev):
@@ -210,3 +269,28 @@ def test_render_rays_fp32_vs_reference_golden(golden, dev):
             got = res[k].cpu()
             assert got.shape == ref.shape
             assert torch.allclose(got, ref, rtol=RTOL, atol=ATOL), (name, k, (got - ref).abs().max().item())
+
+
+def test_render_rays_fp32_benchmark_size_vs_oracle(dev):
+    """BASELINE configs[2] size on the GPU box: 1024 rays x (64 + 128) samples, fp32 MFMA path against the pinned CPU
+    oracle (one oracle forward at this size costs ~1 s of CPU), perturb=1, noise_std=1, replayed RNG draws."""
+    B, S, N = 1024, 64, 128
+    params = [O.make_params(31, 4.0, 0.2), O.make_params(32, 4.0, 0.2)]
+    rays = O.make_rays(77, B, "blender")
+    rng = O.draw_rng(5, B, S, N, 1.0)
+    kw = dict(N_samples=S, use_disp=False, perturb=1.0, noise_std=1.0, N_importance=N, white_back=True, test_time=False)
+    ref = O.render_rays(params, rays, S, False, 1.0, 1.0, N, True, False, rng=rng)
+    ms, emb = build_models(params, dev, "fp32")
+    with torch.no_grad():
+        res = hip_render(ms, emb, rays, kw, rng, dev)
+    assert sorted(res.keys()) == sorted(ref.keys())
+    for k in ref:
+        got = res[k].cpu()
+        assert got.shape == ref[k].shape
+        # importance samples that land on the other side of a coarse sample (1-ulp cdf differences) change single
+        # rays by more than 1e-4: at most a handful of the 1024 rays may do so, the rest hold the 1e-4 bound
+        bad = ~torch.isclose(got, ref[k], rtol=RTOL, atol=ATOL)
+        frac = bad.float().mean().item()
+        assert frac <= 2e-3, (k, frac, (got - ref[k]).abs().max().item())
+        print("render_rays 1024x(64+128) fp32 vs oracle: %s max |diff| %.2e, outside 1e-4: %d of %d"
+              % (k, (got - ref[k]).abs().max().item(), int(bad.sum()), bad.numel()))
