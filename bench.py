@@ -1,6 +1,6 @@
 """bench.py — rays/sec of the NeRF hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--mode train|render]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16_f8|bf16|fp32] [--mode train|render]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -28,9 +28,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
-FLOP_PER_POINT_BWD = 2302208       # dX chain 557,696 MAC (no dX into the encodings) + dW 593,408 MAC
+FLOP_PER_POINT_DX = 1115392        # backward chain: 557,696 MAC (no dX into the encodings)
+FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks (the fp8 dW GEMM
+                                                                    # of bf16_f8 is priced against the bf16 peak as well)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 
 
 def parse():
@@ -38,7 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16_f8", "fp32"])
+    ap.add_argument("--dtype", default="bf16_f8", choices=["bf16", "bf16_f8", "fp32"],
+                    help="bf16_f8 (default): bf16 MFMA forward + dX chain, saved activations/dY stored as block-scaled e4m3 for the "
+                         "dW GEMM; bf16: the same with bf16 storage; fp32: exact-fp32 MFMA (parity configuration)")
     ap.add_argument("--mode", default="train", choices=["train", "render", "eval"])
     ap.add_argument("--image-rays", type=int, default=640000, help="--mode eval: rays per image (800x800), sharded over ranks")
     ap.add_argument("--rays", type=int, default=1024)
@@ -47,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the training step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--fixed-batch", action="store_true", help="replay one resident batch instead of drawing a fresh one per step")
     return ap.parse_args()
 
 
@@ -138,6 +144,83 @@ def cpu_baseline(B, S, N, seconds, train):
                       % (reps, what, B, S, N, dt)}
 
 
+def synth_store(seed, dev, n_img=20, hw=200):
+    """Device-resident synthetic training set in the reference's Blender layout (blender.py:42-69): camera poses on a
+    radius-4 sphere looking at the origin + random pixel colours; batches are drawn and their rays generated on the GPU
+    (nerf_pl_amd.rays.RayStore), so a training batch never crosses PCIe."""
+    from nerf_pl_amd.rays import RayStore
+    g = torch.Generator().manual_seed(seed)
+    c = torch.nn.functional.normalize(torch.randn(n_img, 3, generator=g), dim=-1) * 4.0
+    fwd = torch.nn.functional.normalize(-c, dim=-1)                       # camera looks down its -z axis at the origin
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.nn.functional.normalize(torch.cross(fwd, up, dim=-1), dim=-1)
+    upv = torch.cross(right, fwd, dim=-1)
+    poses = torch.stack([right, upv, -fwd, c], -1).float().contiguous()   # (n_img, 3, 4) = [R | t]
+    rgbs = torch.rand(n_img * hw * hw, 3, generator=g)
+    return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.3, 2.0, 6.0)
+
+
+def event_time(fn, reps, warm=3):
+    """Average / min microseconds per call of `fn` by HIP events on torch's current stream (where libnerfhip launches)."""
+    for _ in range(warm):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    us = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(reps))
+    return sum(us) / len(us), us[0]
+
+
+def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
+    """Per-kernel roofline entries for the MLP kernels of the TIMED training step (fine pass B x (S+N) points and coarse
+    pass B x S points): HIP-event time of each kernel launched alone on resident buffers, algorithmic FLOPs and HBM bytes
+    (DESIGN.md §6), fractions of the 2.5 PFLOP/s dense bf16 MFMA peak and of the 8 TB/s HBM peak."""
+    from nerf_pl_amd import _lib, ops
+    lib = _lib.load()
+    code = ops.mlp_dtype_code(dtype)
+    B = rays.shape[0]
+    out = []
+    with torch.no_grad():
+        z = ops.sample_coarse_z(rays, S, False, 0.0)
+        zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
+    for tag, model, zz in (("fine", models[1], zf), ("coarse", models[0], z)):
+        P = zz.numel()
+        pk = model.packed_weights(dtype)
+        pb = model.packed_weights_bwd(dtype)
+        acts = ops.alloc_acts(P, dtype, dev)
+        raw = ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts)
+        g_out = torch.randn_like(raw)
+        ws = {}
+        ops.mlp_bwd(g_out, raw, pb, acts, dtype, workspace=ws)
+        act_b, dy_b = acts.numel(), ws["dys"].numel()
+        gate_b = (P + 31) // 32 * 9 * 1024
+        ws_b = int(lib.nerfhip_mlp_dw_workspace_bytes(P, code))
+        rows = [
+            ("mlp_fwd_kernel<save>", lambda: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
+             FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point"),
+            ("mlp_bwd_chain_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
+             FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read"),
+            ("mlp_bwd_dw_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=2, workspace=ws),
+             FLOP_PER_POINT_DW * P, (act_b - gate_b) + dy_b, "every saved activation and dY slab read once"),
+            ("mlp_bwd_reduce_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=4, workspace=ws),
+             0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written"),
+        ]
+        for name, fn, flops, nbytes, what in rows:
+            avg, mn = event_time(fn, 12)
+            tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
+            fm, fh = tf / PEAK_TFLOPS[dtype], gbs / PEAK_HBM_GBS
+            key = "%s|%s|%d" % (name, dtype, P)
+            out.append({"kernel": "%s<%s> %s pass, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
+                        "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
+                        "tflops": round(tf, 1), "gbs": round(gbs, 1), "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                        "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
+        del acts, raw, g_out, ws
+    return out
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block on the
@@ -154,6 +237,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist.get_world_size() != a.gpus:
+            print("[bench] WORLD_SIZE %d != --gpus %d" % (dist.get_world_size(), a.gpus), file=sys.stderr, flush=True)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -164,51 +249,69 @@ def main():
 
     B, S, N = a.rays, a.n_samples, a.n_importance
     hp = Namespace(N_samples=S, N_importance=N, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32,
-                   loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[2, 4, 8], decay_gamma=0.5, white_back=True)
-    system = NeRFSystem(hp)
-    # random-init weights of the named architecture (identical on every rank = DDP replicas), density head
-    # scaled so that opacity is non-trivial
-    system.nerf_coarse.load_state_dict(synth_params(100, 4.0, 0.2))
-    system.nerf_fine.load_state_dict(synth_params(101, 4.0, 0.2))
-    for m in system.models:
-        m.mlp_dtype = a.dtype
-    system = system.to(dev)
+                   loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[2, 4, 8], decay_gamma=0.5, white_back=True,
+                   optimizer="adam", lr_scheduler="steplr")
+
+    def build_system(dtype):
+        system = NeRFSystem(hp)
+        # random-init weights of the named architecture (identical on every rank = DDP replicas), density head
+        # scaled so that opacity is non-trivial
+        system.nerf_coarse.load_state_dict(synth_params(100, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(synth_params(101, 4.0, 0.2))
+        for m in system.models:
+            m.mlp_dtype = dtype
+        system = system.to(dev)
+        (opt,), _ = system.configure_optimizers()
+        return system, opt
+
+    system, opt = build_system(a.dtype)
     models, emb = system.models, system.embeddings
-    (opt,), _ = system.configure_optimizers()
     grad_sync = GradSync(models) if world > 1 else None
-    rays = synth_rays(1234 + rank, B).to(dev)                 # each rank draws its own batch
-    rgbs = torch.rand(B, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
-    batch = {"rays": rays, "rgbs": rgbs}
+    rays = synth_rays(1234 + rank, B).to(dev)                 # fixed batch: render mode, per-kernel timings
+    store = synth_store(4321 + rank, dev)                     # each rank owns its own images and draws its own batches
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
     torch.manual_seed(rank)
+
+    def next_batch():
+        if a.fixed_batch:
+            return {"rays": rays, "rgbs": fixed_rgbs}
+        return store.sample(B, generator=gen)                 # randint + gen_rays + gather on the GPU, inside the timed loop
+    fixed_rgbs = torch.rand(B, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
 
     def render_step():
         with torch.no_grad():
             return rendering.render_rays(models, emb, rays, S, False, 1.0, 0.0, N, 1024 * 32, True)
 
-    # The training step (fwd, loss, bwd, [all-reduce], Adam: ~45 launches) is replayed as ONE hipGraph after 3 eager
+    # The training step (fwd, loss, bwd, [all-reduce], Adam: ~40 launches) is replayed as ONE hipGraph after 3 eager
     # steps; same work per step, ~15 us of host time instead of ~1.5 ms.  Falls back to eager issue if capture fails.
-    state = {"graphed": GraphedTrainStep(system, opt, grad_sync, warmup=3) if (a.mode == "train" and not a.no_graph) else None}
+    def make_stepper(system_, opt_, sync_):
+        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3) if not a.no_graph else None}
 
-    def eager_step():
-        out = system.training_step(batch, 0)
-        opt.zero_grad(set_to_none=True)
-        out["loss"].backward()
-        if grad_sync is not None:
-            grad_sync.sync()
-        opt.step()
-        return out
+        def eager(batch):
+            out = system_.training_step(batch, 0)
+            opt_.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            if sync_ is not None:
+                sync_.sync()
+            opt_.step()
+            return out
 
-    def train_step():
-        g = state["graphed"]
-        if g is None:
-            return eager_step()
-        try:
-            return g(batch)
-        except Exception as e:  # noqa: BLE001 - capture problems must not kill the benchmark
-            print("[bench] hipGraph capture failed (%s: %s); continuing eagerly" % (type(e).__name__, e), file=sys.stderr, flush=True)
-            state["graphed"] = None
-            torch.cuda.synchronize()
-            return eager_step()
+        def step_():
+            batch = next_batch()
+            g = st["graphed"]
+            if g is None:
+                return eager(batch)
+            try:
+                return g(batch)
+            except Exception as e:  # noqa: BLE001 - capture problems must not kill the benchmark
+                print("[bench] hipGraph capture failed (%s: %s); continuing eagerly" % (type(e).__name__, e), file=sys.stderr, flush=True)
+                st["graphed"] = None
+                torch.cuda.synchronize()
+                return eager(batch)
+        return step_, st
+
+    train_step, state = make_stepper(system, opt, grad_sync)
 
     # --mode eval (BASELINE.json configs[4]): one step = one full 800x800 image through eval.py's batched_inference
     # contract (32768-ray chunks, test_time: sigma-only coarse pass), each chunk a hipGraph replay; the ray list is
@@ -224,8 +327,6 @@ def main():
         return render_sharded(eval_state["gr"], eval_state["rays"], keys=("rgb_fine", "depth_fine"))
 
     step = train_step if a.mode == "train" else (eval_step if a.mode == "eval" else render_step)
-    for _ in range(max(a.warmup, 5) if a.mode == "train" else a.warmup):     # >= 5: 3 eager + capture + 1 replay
-        step()
 
     def sync():
         torch.cuda.synchronize()
@@ -233,19 +334,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step_fn, warmup, steps):
+        for _ in range(warmup):
+            step_fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
+
+    dt = timed(step, max(a.warmup, 5) if a.mode == "train" else a.warmup, a.steps)     # >= 5: 3 eager + capture + 1 replay
 
     if rank == 0:
         extra = {}
+        traffic_db = {}
+        if os.path.exists(TRAFFIC_JSON):
+            with open(TRAFFIC_JSON) as fh:
+                traffic_db = json.load(fh)
         if a.mode == "train":                                  # forward-only rate of the same workload
             for _ in range(5):
                 render_step()
@@ -256,58 +367,51 @@ def main():
             torch.cuda.synchronize()
             extra["render_fwd_rays_per_s_per_gpu"] = round(B * 30 / (time.perf_counter() - t1), 1)
 
-        # ---- dominant kernel: fine-pass fused MLP forward (B x (S+N) points); HIP events on the launch
-        # stream (kernels are launched on torch's current stream, which is what torch.cuda.Event times) ----
+        # ---- the north-star kernel: fine-pass fused MLP forward, inference variant (B x (S+N) points) ----
         with torch.no_grad():
             z = ops.sample_coarse_z(rays, S, False, 0.0)
             zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
             pk = models[1].packed_weights()                     # pack once: the events bracket the MLP kernel alone
-            for _ in range(5):
-                ops.mlp_fwd_rays(rays, zf, pk, False, a.dtype)
-            reps = 30
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-            ev[0].record()
-            for i in range(reps):
-                ops.mlp_fwd_rays(rays, zf, pk, False, a.dtype)
-                ev[i + 1].record()
-            torch.cuda.synchronize()
-            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
-            avg_ms = sum(ms) / len(ms)
+            avg_us, min_us = event_time(lambda: ops.mlp_fwd_rays(rays, zf, pk, False, a.dtype), 30, warm=5)
         flops = FLOP_PER_POINT_FULL * B * (S + N)
-        ach = flops / (avg_ms * 1e-3) / 1e12
-        kname = "mlp_fwd_kernel<%s,rays,full> %dx%d points" % (a.dtype, B, S + N)
-        traffic = None      # HBM bytes per launch from the PMC passes of the same command (profiles/), else null
-        if os.path.exists(TRAFFIC_JSON):
-            with open(TRAFFIC_JSON) as fh:
-                traffic = json.load(fh).get("mlp_fwd_%s_%dx%d" % (a.dtype, B, S + N), {}).get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": kname,
-                "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic,
-                "avg_launch_us": round(avg_ms * 1e3, 2), "min_launch_us": round(ms[0] * 1e3, 2)}
-        extra["roofline"] = roof
+        ach = flops / avg_us / 1e6
+        ns = {"bound": "mfma", "kernel": "mlp_fwd_kernel<%s,rays,full> (inference) %dx%d points" % (a.dtype, B, S + N),
+              "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+              "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
+              "traffic": traffic_db.get("mlp_fwd_kernel|%s|%d" % (a.dtype, B * (S + N)), {}).get("hbm_bytes_per_launch"),
+              "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min_us, 2)}
         if a.mode == "train":
-            # backward of the same fine pass: fwd(save) once, then nerfhip_mlp_bwd = chain + dW + reduce kernels
-            acts = ops.alloc_acts(B * (S + N), a.dtype, dev)
-            out_f = ops.mlp_fwd_rays(rays, zf, models[1].packed_weights(), False, a.dtype, save=acts)
-            g_out = torch.randn_like(out_f)
-            pb = models[1].packed_weights_bwd()
-            for _ in range(3):
-                ops.mlp_bwd(g_out, out_f, pb, acts, a.dtype)
-            evb = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
-            evb[0].record()
-            for i in range(10):
-                ops.mlp_bwd(g_out, out_f, pb, acts, a.dtype)
-                evb[i + 1].record()
-            torch.cuda.synchronize()
-            bms = sum(evb[i].elapsed_time(evb[i + 1]) for i in range(10)) / 10
-            bach = FLOP_PER_POINT_BWD * B * (S + N) / (bms * 1e-3) / 1e12
-            extra["roofline_bwd"] = {"bound": "hbm+mfma", "kernel": "nerfhip_mlp_bwd<%s> = bwd_chain + bwd_dw + reduce, %dx%d points"
-                                     % (a.dtype, B, S + N), "achieved": round(bach, 2), "peak": PEAK_TFLOPS[a.dtype],
-                                     "unit": "TFLOP/s", "frac": round(bach / PEAK_TFLOPS[a.dtype], 4),
-                                     "avg_launch_us": round(bms * 1e3, 2)}
-            del acts, out_f, g_out
+            # ---- the kernels the TIMED step runs, one entry each; `roofline` = the one that takes the most time ----
+            table = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db)
+            dom = max(table, key=lambda r: r["avg_launch_us"])
+            roof = {"bound": dom["bound"], "kernel": dom["kernel"],
+                    "achieved": dom["gbs"] if dom["bound"] == "hbm" else dom["tflops"],
+                    "peak": PEAK_HBM_GBS if dom["bound"] == "hbm" else PEAK_TFLOPS[a.dtype],
+                    "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s",
+                    "frac": dom["frac_hbm"] if dom["bound"] == "hbm" else dom["frac_mfma"],
+                    "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "frac_mfma": dom["frac_mfma"],
+                    "frac_hbm": dom["frac_hbm"]}
+            extra["roofline"] = roof
+            extra["roofline_kernels"] = table
+            extra["roofline_north_star"] = ns
+            extra["mlp_kernels_us_per_step"] = round(sum(r["avg_launch_us"] for r in table), 1)    # <= ms_per_step * 1000
+            # whole-step MFMA fraction: algorithmic FLOPs of the step (GEMMs only) over the step time
+            step_flops = (FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW) * B * (2 * S + N)
+            extra["step_frac_mfma"] = round(step_flops / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
+            if a.dtype == "bf16_f8" and world == 1:
+                # the same step with bf16 storage of the saved tensors (no fp8 anywhere), for reference
+                sys2, opt2 = build_system("bf16")
+                step2, _ = make_stepper(sys2, opt2, None)
+                dt2 = timed(step2, 6, 15)
+                extra["bf16_storage_ms_per_step"] = round(dt2 / 15 * 1e3, 4)
+                del sys2, opt2, step2
+        else:
+            extra["roofline"] = ns
 
         total_rays = (a.image_rays if a.mode == "eval" else world * B) * a.steps
+        arith = {"bf16_f8": "bf16", "bf16": "bf16", "fp32": "f32"}[a.dtype]
+        mlp_note = {"bf16_f8": "bf16 MFMA MLP (forward + dX chain), dW GEMM on block-scaled e4m3 copies of the saved tensors",
+                    "bf16": "bf16 MFMA MLP", "fp32": "exact-fp32 MFMA MLP"}[a.dtype]
         out = {
             "metric": ("rays/sec (64+128 samples), full training step: render_rays fwd + MSE + bwd + grad all-reduce + Adam"
                        if a.mode == "train" else
@@ -317,13 +421,16 @@ def main():
             "value": round(total_rays / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if a.mode == "eval" else "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": arith, "data": "synthetic",
             "config": {"workload": ("configs[4]: %d-ray image in 32768-ray chunks x (%d+%d) samples, test_time, NeRF D8 W256 "
-                                    "coarse(sigma-only)+fine, %s MFMA MLP, mode=eval" % (a.image_rays, S, N, a.dtype))
+                                    "coarse(sigma-only)+fine, %s, mode=eval" % (a.image_rays, S, N, mlp_note))
                                    if a.mode == "eval" else
                                    ("configs[2]: %d rays/GPU x (%d+%d) samples, NeRF D8 W256 coarse+fine, perturb=1 "
-                                    "noise_std=0 white_back, %s MFMA MLP, mode=%s" % (B, S, N, a.dtype, a.mode)),
+                                    "noise_std=0 white_back, %s, mode=%s" % (B, S, N, mlp_note, a.mode)),
+                       "mlp_dtype": a.dtype,
                        "rays_per_gpu": (a.image_rays // world if a.mode == "eval" else B), "N_samples": S, "N_importance": N,
+                       "batches": ("one resident batch replayed" if (a.fixed_batch or a.mode != "train") else
+                                   "fresh RayStore.sample(%d) per step inside the timed loop (pixel ids -> rays on the GPU)" % B),
                        "issue": ("hipGraph replay of the whole step" if (a.mode == "train" and state["graphed"] is not None
                                                                          and state["graphed"].graph is not None)
                                  else "hipGraph replay per 32768-ray chunk" if a.mode == "eval" else "eager"),

@@ -158,6 +158,13 @@ int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void*
                     void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
                     int accumulate, int dtype, nerfhip_stream_t stream);
 
+/* The same with a phase mask (measurement: bench.py times the three kernels of the backward separately with HIP events):
+ * bit 0 = backward chain (writes dys), bit 1 = weight-gradient GEMM (reads acts + dys, writes dw_workspace),
+ * bit 2 = reduce (dw_workspace -> gradients).  nerfhip_mlp_bwd == phases 7.                                          */
+int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
+                           void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
+                           int accumulate, int dtype, int phases, nerfhip_stream_t stream);
+
 /* ---- N2. MSELoss.forward + psnr + backward seed  (losses.py:9-14, metrics.py:4-13, train.py:103-117) ----
  * rgb_coarse, rgb_fine (NULL when N_importance == 0), target: n = 3*rays floats each.
  * out3 = [loss, psnr of the fine (else coarse) image, its mse];  g_coarse / g_fine (NULL ok) receive

@@ -23,8 +23,9 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-OBJ = os.path.join(PKG, "build")
-LIB = os.path.join(PKG, "libnerfhip.so")
+TAG = os.environ.get("NERFHIP_BUILD_TAG", "")          # A/B kernel builds: objects in build_<tag>/, library in variants/
+OBJ = os.path.join(PKG, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(PKG, "variants", "libnerfhip_%s.so" % TAG) if TAG else os.path.join(PKG, "libnerfhip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 EXTRA = [f for f in os.environ.get("NERFHIP_EXTRA_FLAGS", "").split() if f]     # A/B kernel builds (-DNERFHIP_...=)
@@ -93,6 +94,7 @@ def _compile(job):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     jobs = _jobs()
     todo = []
     for job in jobs:

@@ -7,6 +7,9 @@
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2     // cache-policy bits of the write-once stores: 2 = nt
 #endif
+#ifndef NERFHIP_F8EXP
+#define NERFHIP_F8EXP 0         // timing experiments only (results invalid): 1 = convert but do not store, 2 = store without converting
+#endif
 
 namespace nerfhip {
 using namespace mlp;
@@ -53,36 +56,9 @@ __device__ __forceinline__ void slab_to_f8(const bf16x8& s, float scale, unsigne
     d0 = a.w;
     d1 = b.w;
 }
-// Scale table: one DWORD per pair (the e8m0 byte, zero-extended) at dword index f8_x_scale_pos / f8_dy_scale_pos — the dW
-// kernel DMAs single dwords of it into LDS and hands them to the MFMA as scale operands (byte 0).  The <= 8 scales of a
-// 16-slab section are wave-uniform (SGPRs); lane 0 writes them as two 16-byte stores when the section is complete.
-struct F8Scales {
-    int v[8];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0;
-    }
-    __device__ __forceinline__ void set(int idx, int byte) { v[idx] = byte; }      // idx: compile-time constant
-};
-__device__ __forceinline__ void save_scales_f8(int& pending, uint8_t* tile_ptr, int scale_off, int pos0, const F8Scales& sc,
-                                               int lane) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + scale_off + 4 * pos0, 0, 32, 0x00020000);
-    u32x4 lo, hi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lo[i] = (unsigned)sc.v[i];
-        hi[i] = (unsigned)sc.v[4 + i];
-    }
-    // lanes 1..63 fall outside the 32-byte descriptor and are dropped by the bounds check: no exec juggling needed
-    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, (unsigned)lane * 32u, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, (unsigned)lane * 32u + 16u, 0, 0);
-    pending += 2;
-}
-// store slab pair `pair` (slabs 2*pair, 2*pair+1; `mx` = this lane's max |value| over both) as one e4m3 piece; returns the
-// pair's e8m0 scale byte (wave-uniform)
-__device__ __forceinline__ int save_pair_f8(int& pending, uint8_t* tile_ptr, int pair, const bf16x8& s0, const bf16x8& s1,
-                                            float mx, int lane) {
-    const int sb = f8_scale_byte(wave_max_u32(__float_as_uint(mx)));
+// slab pair (slabs 2*pair, 2*pair+1) as one e4m3 piece under the (wave-uniform) scale byte `sb`
+__device__ __forceinline__ void save_pair_f8(int& pending, uint8_t* tile_ptr, int pair, const bf16x8& s0, const bf16x8& s1, int sb,
+                                             int lane) {
     const float scale = __uint_as_float((unsigned)sb << 23);
     u32x4 pk;
     unsigned d0, d1;
@@ -90,10 +66,57 @@ __device__ __forceinline__ int save_pair_f8(int& pending, uint8_t* tile_ptr, int
     pk[0] = d0; pk[1] = d1;
     slab_to_f8(s1, scale, d0, d1);
     pk[2] = d0; pk[3] = d1;
+#if NERFHIP_F8EXP == 1
+    asm volatile("" ::"v"(pk));
+#else
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + (size_t)pair * kPieceBytes, 0, kPieceBytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (unsigned)lane * 16u, 0, NERFHIP_STORE_AUX);     // soffset 0: see save_slabs
+    __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (unsigned)lane * 16u, 0, NERFHIP_STORE_AUX);
     pending += 1;
-    return sb;
+#endif
 }
+// one scale dword (activations: one per (wave tile, section)), written by lane 0
+__device__ __forceinline__ void save_scale_f8(int& pending, uint8_t* tile_ptr, int scale_off, int index, int sb, int lane) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + scale_off + 4 * index, 0, 4, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)sb, rs, (unsigned)lane * 4u, 0, 0);      // lanes 1..63: out of bounds, dropped
+    pending += 1;
+}
+// ---- e5m2 ("bf8") variant for dY: 5 exponent bits keep the heavy tail of the per-point gradient magnitudes (samples off the
+// surface carry dY 1e-3 .. 1e-6 of the tile's maximum; e4m3's 14 binades of normals under ONE scale per tile flush them)
+__device__ __forceinline__ int bf8_scale_byte(unsigned maxbits) {     // |x| / 2^(E-127) < 2^15 <= 57344 (e5m2 max)
+    const int e = (int)((maxbits >> 23) & 0xffu) - 14;
+    return e < 1 ? 1 : e;
+}
+__device__ __forceinline__ void slab_to_bf8(const bf16x8& s, float scale, unsigned& d0, unsigned& d1) {
+    union { bf16x8 v; bf16x2v p[4]; } u;
+    u.v = s;
+    union { s16x2 h; unsigned w; } a, b;
+    a.w = 0u;
+    b.w = 0u;
+    a.h = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(a.h, u.p[0], scale, false);
+    a.h = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(a.h, u.p[1], scale, true);
+    b.h = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(b.h, u.p[2], scale, false);
+    b.h = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(b.h, u.p[3], scale, true);
+    d0 = a.w;
+    d1 = b.w;
+}
+__device__ __forceinline__ void save_pair_bf8(int& pending, uint8_t* tile_ptr, int pair, const bf16x8& s0, const bf16x8& s1, int sb,
+                                              int lane) {
+    const float scale = __uint_as_float((unsigned)sb << 23);
+    u32x4 pk;
+    unsigned d0, d1;
+    slab_to_bf8(s0, scale, d0, d1);
+    pk[0] = d0; pk[1] = d1;
+    slab_to_bf8(s1, scale, d0, d1);
+    pk[2] = d0; pk[3] = d1;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + (size_t)pair * kPieceBytes, 0, kPieceBytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (unsigned)lane * 16u, 0, NERFHIP_STORE_AUX);
+    pending += 1;
+}
+__device__ __forceinline__ int bf8_block_scale(float lane_max) { return bf8_scale_byte(wave_max_u32(__float_as_uint(lane_max))); }
+#ifndef NERFHIP_F8_DY_E5M2
+#define NERFHIP_F8_DY_E5M2 1
+#endif
+// scale byte of a block from the lanes' partial maxima (one DPP reduction)
+__device__ __forceinline__ int f8_block_scale(float lane_max) { return f8_scale_byte(wave_max_u32(__float_as_uint(lane_max))); }
 
 }  // namespace nerfhip

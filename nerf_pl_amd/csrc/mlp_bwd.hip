@@ -224,12 +224,12 @@ __device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_
 // acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(pre-act), read as ONE 16-B
 // gate word per lane per layer (bit 8*ks+j, written by the forward's SAVE variant; mask_piece < 0 = no gate),
 // store as dY section, keep as next B operand.
-// F8: the section is stored as e4m3 slab pairs (f8_store.h); `sc`/`sc0` = the scale-table section being assembled and the
-// index of this section's first pair in it; `dy_tile` = base of the tile's dY block.
+// F8: the section is stored as e4m3 slab pairs under ONE scale per (wave tile, layer) — a single DPP reduction at the layer
+// end (f8_store.h), recorded in the tile's scale table; `dy_tile` = base of the tile's dY block.
 template <int PREC, bool MASK, bool F8, int NT, typename Slab>
 __device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t acts,
                                              int gate_off, int mask_piece, __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile,
-                                             int dy_sec, Slab* out, int lane, F8Scales* sc, int sc0) {
+                                             int dy_sec, Slab* out, int lane) {
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
         gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
@@ -246,16 +246,19 @@ __device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (
             if (F8) mx = fmaxf(mx, fabsf(v[j]));
         }
         mk_slab(out[ks], v);
-        if constexpr (F8) {
-            if constexpr (PREC == NERFHIP_BF16) {
-                if (ks & 1) {
-                    sc->set(sc0 + (ks >> 1), save_pair_f8(st.pending, dy_tile, (dy_sec + ks) / 2, out[ks - 1], out[ks], mx, lane));
-                    mx = 0.0f;
-                }
-            }
-        } else {
-            store_slab(st, dys, dy_sec + ks, out[ks], lane);
-        }
+        if constexpr (!F8) store_slab(st, dys, dy_sec + ks, out[ks], lane);
+    }
+    if constexpr (F8 && PREC == NERFHIP_BF16) {
+#if NERFHIP_F8_DY_E5M2
+        const int sb = bf8_block_scale(mx);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) save_pair_bf8(st.pending, dy_tile, dy_sec / 2 + q, out[2 * q], out[2 * q + 1], sb, lane);
+#else
+        const int sb = f8_block_scale(mx);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) save_pair_f8(st.pending, dy_tile, dy_sec / 2 + q, out[2 * q], out[2 * q + 1], sb, lane);
+#endif
+        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
     }
 }
 
@@ -287,8 +290,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
         const_cast<uint8_t*>(acts_base) + (size_t)tile * kActTile, 0, kActTile, 0x00020000);
     uint8_t* dy_tile = dys_base + (size_t)tile * kDyTile;
     __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(dy_tile, 0, kDyTile, 0x00020000);
-    F8Scales sc;
-    sc.clear();
+
 
     BwdStream<PREC> st;
     st.gsrc = packed_bwd + lane * 16;
@@ -317,9 +319,17 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     }
     if constexpr (F8) {
         if constexpr (PREC == NERFHIP_BF16) {
-            // scale-table bytes 0..7: rgb, sigma, -, -, dir pairs 1..4 (mlp_layout.h: f8_dy_scale_pos)
-            sc.set(0, save_pair_f8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, slab_absmax8(g_rgb), lane));
-            sc.set(1, save_pair_f8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, slab_absmax8(g_sig), lane));
+#if NERFHIP_F8_DY_E5M2
+            const int sb_rgb = bf8_block_scale(slab_absmax8(g_rgb)), sb_sig = bf8_block_scale(slab_absmax8(g_sig));
+            save_pair_bf8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, sb_rgb, lane);
+            save_pair_bf8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, sb_sig, lane);
+#else
+            const int sb_rgb = f8_block_scale(slab_absmax8(g_rgb)), sb_sig = f8_block_scale(slab_absmax8(g_sig));
+            save_pair_f8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, sb_rgb, lane);
+            save_pair_f8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, sb_sig, lane);
+#endif
+            save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(kDyRgb), sb_rgb, lane);
+            save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(kDySigma), sb_sig, lane);
         }
     } else {
         store_slab(st, dys, kDyRgb, g_rgb, lane);
@@ -333,27 +343,20 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     {
         f32x16 a4[4];
         run_bwd_layer<PREC, 0, 4, 1>(st, smem_lane, &g_rgb, a4);
-        finish_layer<PREC, true, F8>(st, a4, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir, gd, lane, &sc, 4);
-        if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), 0, sc, lane);
+        finish_layer<PREC, true, F8>(st, a4, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir, gd, lane);
     }
     // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)
     f32x16 acc[8];
     Slab gs[17];
     run_bwd_layer<PREC, 1, 8, 8>(st, smem_lane, gd, acc);
-    sc.clear();
-    finish_layer<PREC, false, F8>(st, acc, acts, kGateOff, 0, dys, dy_tile, kDyFeat, gs, lane, &sc, 0);
-    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(kDyFeat / 2), sc, lane);
+    finish_layer<PREC, false, F8>(st, acc, acts, kGateOff, 0, dys, dy_tile, kDyFeat, gs, lane);
     gs[16] = g_sig;
     // final^T + sigma^T : g_h8 ; mask with h8
     run_bwd_layer<PREC, 2, 8, 17>(st, smem_lane, gs, acc);
-    sc.clear();
-    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8), gs, lane, &sc, 0);
-    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(dy_h(8) / 2), sc, lane);
+    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8), gs, lane);
 #define NH_BWD(L)                                                                     \
     run_bwd_layer<PREC, L, 8, 16>(st, smem_lane, gs, acc);                             \
-    sc.clear();                                                                        \
-    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), gs, lane, &sc, 0); \
-    if constexpr (F8) save_scales_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_scale_pos(dy_h(10 - L) / 2), sc, lane);
+    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), gs, lane);
     NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
 #undef NH_BWD
 }
@@ -614,15 +617,12 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __rest
 
     // DMA source unit of LDS unit `lane` (see the header comment): global lane 32 h + 8 g + (n & 7)
     const int dma_unit = ((lane >> 3) & 1) * 32 + 8 * (lane >> 4) + (lane & 7);
-    // scale DMA: lane i < 32 -> (tile i >> 4, slot i & 15): slot 0 = this wave's dY pair, slot 1 + x = X pair x
+    // scale DMA: lane i < 32 -> (tile i >> 4, slot i & 15) lands at dword i of the wave's scale area: slot 0 = the dY
+    // section's scale, slot 1 = the x1 section's, slots >= 2 = the x2 section's (x1's when there is no x2)
     const int s_tile = (lane >> 4) & 1, s_slot = lane & 15;
-    int s_from_dy, s_pos;
-    {
-        const int xq = (s_slot >= 1 && s_slot - 1 < n_xt) ? s_slot - 1 : 0;
-        const int xpos = xq < x1p ? f8_x_scale_pos(x1_pair0 + xq) : f8_x_scale_pos(x2_pair0 + xq - x1p);
-        s_from_dy = (s_slot == 0) ? 1 : 0;
-        s_pos = s_from_dy ? f8_dy_scale_pos(dy_pair0 + (wave < n_ot ? wave : 0)) : xpos;
-    }
+    const int s_from_dy = s_slot == 0;
+    const int s_pos = s_from_dy ? f8_dy_section(jb.dy_off)
+                                : ((s_slot == 1 || x2p == 0) ? f8_x_section(jb.x1_off) : f8_x_section(jb.x2_off));
     auto issue_stage = [&](int64_t it) {
         int64_t P = p_first + (it < my_pairs ? it : my_pairs - 1);                   // past the end: re-fetch the last pair
         if (P >= npairs) P = npairs - 1;
@@ -690,13 +690,14 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __rest
             };
             const i32x8 a = load_frag(wave);
             const int sa = *reinterpret_cast<const int*>(sc_base);
-            accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, 0, 0, 0, sa, 0, 127);
+            const int sx1 = *reinterpret_cast<const int*>(sc_base + 4), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
+            accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, 127);   // bias: dY x 1.0
 #pragma unroll
             for (int x = 0; x < kDwMaxXTiles; ++x) {
                 if (x < n_xt) {
                     const i32x8 b = load_frag(dyp + x);
-                    const int sb = *reinterpret_cast<const int*>(sc_base + 4 * (1 + x));
-                    acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[x], 0, 0, 0, sa, 0, sb);
+                    // A = dY: e5m2 (cbsz 1), B = X: e4m3 (blgp 0); lanes 0..31 carry tile T0's section scales, lanes 32..63 T1's
+                    acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[x], NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, x < x1p ? sx1 : sx2);
                 }
             }
         }
@@ -872,9 +873,10 @@ extern "C" size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype) {
     return (size_t)nerfhip_mlp_dw_splits(n_points, dtype) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
 }
 
-extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
-                               const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
-                               float* const* grad_b_host, int accumulate, int dtype, nerfhip_stream_t stream) {
+extern "C" int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
+                                      const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
+                                      float* const* grad_b_host, int accumulate, int dtype, int phases,
+                                      nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n >= 0);
     if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
     NERFHIP_CHECK_ARG(grad_w_host && grad_b_host);
@@ -893,25 +895,41 @@ extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, 
     nerfhip::DwJobTable jt;
     const int nwg = dw_plan(n, dtype, &jt);
     const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs);
+    const bool do_chain = phases & 1, do_dw = phases & 2, do_reduce = phases & 4;
     if (dtype == NERFHIP_BF16_F8) {
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, tiles, (const uint8_t*)acts,
-                           (const uint8_t*)dys, (float*)dw_workspace);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
+        if (do_chain)
+            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s,
+                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        if (do_dw)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, tiles, (const uint8_t*)acts,
+                               (const uint8_t*)dys, (float*)dw_workspace);
+        if (do_reduce)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
         return nerfhip_launch_status();
     }
     if (dtype == NERFHIP_BF16) {
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, tiles,
-                           (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+        if (do_chain)
+            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s,
+                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        if (do_dw)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, tiles,
+                               (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     } else {
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, tiles,
-                           (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+        if (do_chain)
+            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s,
+                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        if (do_dw)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, tiles,
+                               (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
     }
-    hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
+    if (do_reduce)
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
     return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
+                               const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
+                               float* const* grad_b_host, int accumulate, int dtype, nerfhip_stream_t stream) {
+    return nerfhip_mlp_bwd_phases(g_out, out, n, packed_bwd, acts, dys, dw_workspace, grad_w_host, grad_b_host, accumulate,
+                                  dtype, 7, stream);
 }

@@ -211,10 +211,15 @@ __device__ __forceinline__ float slab_absmax(const bf16x8& s) {
 // all waves being chunk-synchronised by the weight ring's barriers — it used to stall every SIMD's MFMA pipe at once.
 // Weights are packed in the same (t, ks) order (mlp_pack.hip); fragment i = t*NKS + ks = piece G0 + 1 + i*PPF.
 //   out != nullptr : `out[2t], out[2t+1]` receive the activated slabs;   heads (NT == 1) return the raw tile in *raw.
+// fp8 storage (SV == 2): a layer stores its INPUT slabs (`chain` = the previous layer's activations, section `in_sec`, live in
+// registers for the whole layer) instead of its outputs — pair by pair in its tile epilogues, under the e8m0 scale byte
+// `in_sb` the previous layer computed with ONE wave reduction at its end — and returns the scale byte of its own output
+// (the per-lane max is folded into the epilogues: 8 v_max3 per tile).  The conversions therefore depend on nothing the
+// tile just computed: no reduction latency sits in any tile epilogue (a per-tile scale made this kernel 60 % slower).
 template <int PREC, int L, int NCH, int NT, bool RELU, int SV, typename Slab>
-__device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st, const char* smem_lane, char* bias_priv,
-                                          const char* enc_lds, const Slab* chain, Slab* out, f32x16* raw,
-                                          uint8_t* rsrc, int act_sec, int gate_piece, int lane) {
+__device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st, const char* smem_lane, char* bias_priv,
+                                         const char* enc_lds, const Slab* chain, Slab* out, f32x16* raw,
+                                         uint8_t* rsrc, int act_sec, int gate_piece, int lane, int in_sec = -1, int in_sb = 127) {
     constexpr bool SAVE = SV != 0, F8 = SV == 2;
     static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
     constexpr Layer ly = kLayers[L];
@@ -255,8 +260,8 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st
 
     f32x16 acc[2];
     unsigned gw[4] = {0u, 0u, 0u, 0u};
-    F8Scales fsc;
-    fsc.clear();
+    float mx = 0.0f;                                   // F8: this lane's max |output| of the layer
+
     static_for<0, N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = frag_tile(i, NT, NKS), ks = frag_slab(i, NT, NKS);
@@ -283,11 +288,29 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st
         }
         if constexpr (i + D < N) load_frag(std::integral_constant<int, i + D>{}, a[i % D]);
 
+#ifndef NERFHIP_F8_CVT_AT_START
+#define NERFHIP_F8_CVT_AT_START 0
+#endif
+        if constexpr (ks == (NERFHIP_F8_CVT_AT_START ? 0 : NKS - 1)) {
+            if constexpr (F8 && PREC == NERFHIP_BF16) {
+                // this tile's share of the layer's INPUT pairs (chain_slabs / 2 pairs spread over the NT tiles, issued in
+                // bursts of NERFHIP_F8_BURST tiles' worth: consecutive pairs are contiguous KiBs of HBM)
+#ifndef NERFHIP_F8_BURST
+#define NERFHIP_F8_BURST 1
+#endif
+                constexpr int NP = ly.chain_slabs / 2, BU = (NERFHIP_F8_BURST < NT) ? NERFHIP_F8_BURST : NT;
+                constexpr int q0 = (t % BU == 0) ? t * NP / NT : 0, q1 = (t % BU == 0) ? (t + BU) * NP / NT : 0;
+                if (in_sec >= 0) {
+#pragma unroll
+                    for (int q = q0; q < q1; ++q)
+                        save_pair_f8(st.pending, rsrc, in_sec / 2 + q, chain[2 * q], chain[2 * q + 1], in_sb, lane);
+                }
+            }
+        }
         if constexpr (ks == NKS - 1) {                       // ---- epilogue of tile t ----
             if constexpr (NT == 1) {                         // heads: hand the raw tile back
                 *raw = c;
             } else {
-                float mx = 0.0f;
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     float v[8];
@@ -295,8 +318,10 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st
                     for (int j = 0; j < 8; ++j) {
                         const float x = c[8 * sl + j];
                         v[j] = RELU ? fmaxf(x, 0.0f) : x;
+#if NERFHIP_F8EXP != 3
                         if (F8) mx = fmaxf(mx, RELU ? v[j] : fabsf(v[j]));
-                        if (RELU && SAVE) {
+#endif
+                        if (RELU && SAVE && NERFHIP_F8EXP != 4) {
                             // ReLU gate of value idx = 8*(2t+sl) + j -> word idx>>5, bit 31-(idx&31).  Pure VALU (no
                             // v_cmp: 128 live SGPR lane masks per layer spill): relu(x) is +-0 or positive, so bit 31 of
                             // (bits + 0x7fffffff) is [x > 0]; v_alignbit pushes it into the word.
@@ -307,12 +332,7 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st
                     }
                     make_slab(out[2 * t + sl], v);
                 }
-                if constexpr (F8) {
-                    if constexpr (PREC == NERFHIP_BF16)
-                        fsc.set(t, save_pair_f8(st.pending, rsrc, (act_sec + 2 * t) / 2, out[2 * t], out[2 * t + 1], mx, lane));
-                } else if (SAVE) {
-                    save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
-                }
+                if constexpr (SAVE && !F8) save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
             }
 #if NERFHIP_TILE_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from stretching live ranges across tiles
@@ -324,7 +344,13 @@ __device__ __forceinline__ void run_layer(WeightStream<PREC, NCH, (SV != 0)>& st
         g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
         save_gates(st, rsrc, F8 ? f8_act_gate_off() : act_mask_off(PREC), gate_piece, g, lane);
     }
-    if constexpr (F8 && NT != 1) save_scales_f8(st.pending, rsrc, f8_act_scale_off(), f8_x_scale_pos(act_sec / 2), fsc, lane);
+    if constexpr (F8 && NT != 1) {
+        // scale of this layer's OUTPUT section (one reduction per layer), recorded in the tile's scale table
+        const int sb = f8_block_scale(mx);
+        save_scale_f8(st.pending, rsrc, f8_act_scale_off(), f8_x_section(act_sec), sb, lane);
+        return sb;
+    }
+    return 127;
 }
 
 // ---- input encodings in slot order (mlp_layout.h: enc_slot_channel) -----------------------------
@@ -463,12 +489,12 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 
     if constexpr (F8) {
         if constexpr (PREC == NERFHIP_BF16) {
-            F8Scales esc;
-            esc.clear();
-            esc.set(0, save_pair_f8(st.pending, tile_base, kActEncX / 2, encx[0], encx[1], fmaxf(slab_absmax(encx[0]), slab_absmax(encx[1])), lane));
-            esc.set(1, save_pair_f8(st.pending, tile_base, kActEncX / 2 + 1, encx[2], encx[3], fmaxf(slab_absmax(encx[2]), slab_absmax(encx[3])), lane));
-            esc.set(2, save_pair_f8(st.pending, tile_base, kActEncD / 2, encd[0], encd[1], fmaxf(slab_absmax(encd[0]), slab_absmax(encd[1])), lane));
-            save_scales_f8(st.pending, tile_base, f8_act_scale_off(), 0, esc, lane);
+            // encodings: |sin|,|cos| <= 1 and scene coordinates << 448 => e4m3 under the fixed scale 2^0
+            save_pair_f8(st.pending, tile_base, kActEncX / 2, encx[0], encx[1], 127, lane);
+            save_pair_f8(st.pending, tile_base, kActEncX / 2 + 1, encx[2], encx[3], 127, lane);
+            save_pair_f8(st.pending, tile_base, kActEncD / 2, encd[0], encd[1], 127, lane);
+            save_scale_f8(st.pending, tile_base, f8_act_scale_off(), f8_x_section(kActEncX), 127, lane);
+            save_scale_f8(st.pending, tile_base, f8_act_scale_off(), f8_x_section(kActEncD), 127, lane);
         }
     } else if (SAVE) {
         save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
@@ -485,9 +511,10 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
     Slab ha[16], hb[16];
     f32x16 raw;
-#define NH_LAYER(L, ENC, IN, OUT)                                                                          \
-    run_layer<PREC, L, NCH, 8, true, SV>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
-                                         act_h(L + 1), mask_piece_h(L + 1), lane);
+    int sb = 127;       // e8m0 scale byte of the section produced by the previous layer (F8)
+#define NH_LAYER(L, ENC, IN, OUT)                                                                               \
+    sb = run_layer<PREC, L, NCH, 8, true, SV>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
+                                              act_h(L + 1), mask_piece_h(L + 1), lane, (L) == 0 ? -1 : act_h(L), sb);
     NH_LAYER(0, enc_x, (const Slab*)nullptr, ha)
     NH_LAYER(1, (const char*)nullptr, ha, hb)
     NH_LAYER(2, (const char*)nullptr, hb, ha)
@@ -506,15 +533,14 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         if (valid && h == 0) out[p] = sigma;                // (n,1)   nerf.py:112-114
         return;
     } else {
-        // xyz_encoding_final: no activation (nerf.py:116) -> ha
-        run_layer<PREC, 9, NCH, 8, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, ha, (f32x16*)nullptr,
-                                              tile_base, kActFeat, 0, lane);
-        // dir_encoding: relu(W [feat | dir])  (nerf.py:118-119) -> hb[0..7]
-        run_layer<PREC, 10, NCH, 4, true, SV>(st, smem_lane, smem_half, enc_d, ha, hb, (f32x16*)nullptr, tile_base, kActT,
-                                              kMaskPieceT, lane);
+        // xyz_encoding_final: no activation (nerf.py:116) -> ha   (F8: stores its input h8)
+        sb = run_layer<PREC, 9, NCH, 8, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, ha, (f32x16*)nullptr,
+                                                   tile_base, kActFeat, 0, lane, act_h(8), sb);
+        // dir_encoding: relu(W [feat | dir])  (nerf.py:118-119) -> hb[0..7]   (F8: stores its input feat)
+        sb = run_layer<PREC, 10, NCH, 4, true, SV>(st, smem_lane, smem_half, enc_d, ha, hb, (f32x16*)nullptr, tile_base, kActT,
+                                                   kMaskPieceT, lane, kActFeat, sb);
         run_layer<PREC, 11, NCH, 1, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
-                                               tile_base, 0, 0, lane);
-
+                                               tile_base, 0, 0, lane, kActT, sb);                       // (F8: stores its input t)
         if (valid && h == 0) {
             float4 o;
             o.x = 1.0f / (1.0f + expf(-raw[0]));            // sigmoid   nerf.py:79-81

@@ -235,12 +235,14 @@ constexpr int kDwSlabFloats = 8 * kDwMaxXTiles * 64 * 16 + 8 * 64;
 // The dW GEMM (points = K) is the only consumer of the saved activations X and of dY, and it is bound by the bytes it
 // reads.  In this mode the activation-saving forward and the backward chain store every slab PAIR (2t, 2t+1) — the 32
 // features of one MFMA operand tile, 32 points — as ONE 1 KiB piece of OCP e4m3 bytes, lane (n, h) holding
-// [slab 2t: 8 B | slab 2t+1: 8 B], together with one e8m0 scale byte per (wave tile, pair): the block-scaled ("MX")
-// operand format of v_mfma_scale_f32_32x32x64_f8f6f4, whose 32-wide K blocks are exactly the 32 points of a wave tile.
-//   scale byte E:  stored q = x / 2^(E-127) with E = max(Emax - 7, 1), Emax = biased exponent of the pair's max |x|
-//                  => |q| < 2^8 <= 448 (e4m3 max; v_cvt_scalef32_pk_fp8 does not saturate, it produces NaN above 464)
-// Tile block of X:  [79 pair pieces][9 gate pieces (as before)][1 KiB: scale dwords at index f8_x_scale_pos(pair)]
-// Tile block of dY: [78 pair pieces][1 KiB: scale dwords at index f8_dy_scale_pos(pair)]
+// [slab 2t: 8 B | slab 2t+1: 8 B] — the operand format of v_mfma_scale_f32_32x32x64_f8f6f4, whose 32-wide K blocks are
+// exactly the 32 points of a wave tile:
+// OCP e4m3 with one e8m0 scale byte per (wave tile, 16-slab section = one layer's activations or dY):
+//      stored q = x / 2^(E-127), E = max(Emax - 7, 1), Emax = biased exponent of the block's max |x|
+//      => |q| < 2^8 <= 448 (e4m3 max; v_cvt_scalef32_pk_fp8 does not saturate, it produces NaN above 464).
+// The input encodings (|sin|, |cos| <= 1, coordinates << 448) use the fixed scale 2^0.
+// Tile block of X:  [79 pair pieces][9 gate pieces (as before)][1 KiB: scale dwords, one per SECTION at f8_x_section()]
+// Tile block of dY: [78 pair pieces][1 KiB: scale dwords, one per SECTION at f8_dy_section()]
 constexpr int kF8ActPairs = kActSlabs / 2;          // 79
 constexpr int kF8DyPairs = kDySlabs / 2;            // 78
 NH_HD constexpr int f8_act_gate_off() { return kF8ActPairs * kPieceBytes; }
@@ -248,15 +250,15 @@ NH_HD constexpr int f8_act_scale_off() { return f8_act_gate_off() + kMaskPieces 
 NH_HD constexpr int f8_act_tile_bytes() { return f8_act_scale_off() + kPieceBytes; }                 // 89 KiB (bf16: 167)
 NH_HD constexpr int f8_dy_scale_off() { return kF8DyPairs * kPieceBytes; }
 NH_HD constexpr int f8_dy_tile_bytes() { return f8_dy_scale_off() + kPieceBytes; }                   // 79 KiB (bf16: 156)
-// The scale table holds one DWORD per pair (the byte, zero-extended) at dword index f8_*_scale_pos(pair); positions are
-// laid out so that every 16-slab section starts on a multiple of 8 (its producer writes it with two 16-byte stores): X: encx pairs 0,1 -> bytes 0,1; encd pair 2 -> byte 2; h_l (pairs 3 + 8(l-1) ..) -> 8l ..;
-// feat -> 72 ..; t -> 80 ..83.   dY: rgb pair 0 -> 0; sigma pair 13 -> 1; dir pairs 1..4 -> 4..7; feat pairs 5..12 -> 8..15;
-// dY_l pairs 14 + 8(8-l) .. -> 16 + 8(8-l) ..
-NH_HD constexpr int f8_x_scale_pos(int pair) { return pair < 3 ? pair : pair + 5; }
-NH_HD constexpr int f8_dy_scale_pos(int pair) {
-    return pair == 0 ? 0 : (pair == kDySigma / 2 ? 1 : (pair < kDySigma / 2 ? pair + 3 : pair + 2));
+// Scale tables: one DWORD (the e8m0 byte, zero-extended) per SECTION:
+// section index of an activation slab: 0 encx, 1 encd, 2..9 h1..h8, 10 feat, 11 t
+NH_HD constexpr int f8_x_section(int slab) {
+    return slab < kActEncD ? 0 : (slab < kActH0 ? 1 : (slab < kActFeat ? 2 + (slab - kActH0) / 16 : (slab < kActT ? 10 : 11)));
 }
-constexpr int kF8ScaleDwords = 96;                  // table entries per tile block (both tables fit: 84 / 80 used)
+// section index of a dY slab: 0 rgb, 1 dir, 2 feat, 3 sigma, 4 + (8 - l) dY_l
+NH_HD constexpr int f8_dy_section(int slab) {
+    return slab < kDyDir ? 0 : (slab < kDyFeat ? 1 : (slab < kDySigma ? 2 : (slab < kDyH0 ? 3 : 4 + (slab - kDyH0) / 16)));
+}
 // Operand row m (0..31) of a pair, as ds_read_b64_tr_b8 delivers it to the MFMA: slab 2t + (m >> 4), half (m >> 3) & 1,
 // slot m & 7  (natural order swaps bits 2 and 3 of the in-slab index).
 NH_HD constexpr int f8_row_h(int m) { return (m >> 3) & 1; }

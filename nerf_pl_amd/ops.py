@@ -353,8 +353,10 @@ def pack_weights_bwd(weights, dtype, out=None):
 
 
 @device_guard
-def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
-    """Gradients of all 24 parameter tensors given dL/d(out).  Returns ([gw0..gw11], [gb0..gb11])."""
+def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES, phases=7, workspace=None):
+    """Gradients of all 24 parameter tensors given dL/d(out).  Returns ([gw0..gw11], [gb0..gb11], flat buffer).
+    phases / workspace: measurement hooks (bench.py): run only some of the three kernels (bit 0 chain, 1 dW GEMM, 2 reduce)
+    on caller-kept scratch buffers (dys, dw workspace, flat gradients)."""
     require_gpu(g_out, out)
     code = mlp_dtype_code(dtype)
     g_out = _c(g_out.float()).reshape(-1, 4)
@@ -362,8 +364,13 @@ def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
     n = out.shape[0]
     dev = out.device
     lib = _lib.load()
-    dys = torch.empty(int(lib.nerfhip_mlp_dy_bytes(n, code)), device=dev, dtype=torch.uint8)
-    ws = torch.empty(int(lib.nerfhip_mlp_dw_workspace_bytes(n, code)), device=dev, dtype=torch.uint8)
+    if workspace is not None and "dys" in workspace:
+        dys, ws = workspace["dys"], workspace["ws"]
+    else:
+        dys = torch.empty(int(lib.nerfhip_mlp_dy_bytes(n, code)), device=dev, dtype=torch.uint8)
+        ws = torch.empty(int(lib.nerfhip_mlp_dw_workspace_bytes(n, code)), device=dev, dtype=torch.uint8)
+        if workspace is not None:
+            workspace["dys"], workspace["ws"] = dys, ws
     # one flat fp32 buffer for all 24 gradients (595,844 floats): autograd adopts the views as p.grad,
     # so a model's gradients are contiguous => ONE RCCL all-reduce per model, no flatten copies
     sizes = [s[0] * s[1] for s in shapes] + [s[0] for s in shapes]
@@ -377,6 +384,6 @@ def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES):
     gb = views[12:]
     gwp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in gw])
     gbp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in gb])
-    check(lib.nerfhip_mlp_bwd(ptr(g_out), ptr(out), n, ptr(packed_bwd), ptr(acts), ptr(dys), ptr(ws), gwp, gbp, 0, code,
-                              stream_ptr()), "nerfhip_mlp_bwd")
+    check(lib.nerfhip_mlp_bwd_phases(ptr(g_out), ptr(out), n, ptr(packed_bwd), ptr(acts), ptr(dys), ptr(ws), gwp, gbp, 0, code,
+                                     int(phases), stream_ptr()), "nerfhip_mlp_bwd")
     return gw, gb, flat

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--samples", type=int, default=192)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--interleaved", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = NeRF()
@@ -52,11 +53,33 @@ def main():
     g_out = torch.randn_like(out)
     f_avg, f_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, False, a.dtype), a.reps)
     s_avg, s_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, False, a.dtype, save=acts), a.reps)
-    b_avg, b_min = timed(lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype), a.reps)
+    ws = {}
+    b_avg, b_min = timed(lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype, workspace=ws), a.reps)
+    ph = [timed(lambda ph=ph: ops.mlp_bwd(g_out, out, pb, acts, a.dtype, phases=ph, workspace=ws), a.reps) for ph in (1, 2, 4)]
     so_avg, so_min = timed(lambda: ops.mlp_fwd_rays(rays, z, packed, True, a.dtype), a.reps)
-    print("%s %dx%d %s: fwd %.1f (min %.1f)  fwd_sigma %.1f  fwd+save %.1f (min %.1f)  bwd %.1f (min %.1f) us"
+    if a.interleaved:
+        # the training step's order: [pack, fwd+save, chain, dW, reduce] repeated, every kernel bracketed by events
+        names = ["pack", "fwd+save", "chain", "dW", "reduce"]
+        fns = [lambda: m.packed_weights(a.dtype),
+               lambda: ops.mlp_fwd_rays(rays, z, packed, False, a.dtype, save=acts),
+               lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype, phases=1, workspace=ws),
+               lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype, phases=2, workspace=ws),
+               lambda: ops.mlp_bwd(g_out, out, pb, acts, a.dtype, phases=4, workspace=ws)]
+        tot = [0.0] * len(fns)
+        for rep in range(a.reps + 3):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)]
+            evs[0].record()
+            for i, f in enumerate(fns):
+                f()
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            if rep >= 3:
+                for i in range(len(fns)):
+                    tot[i] += evs[i].elapsed_time(evs[i + 1]) * 1e3
+        print("   interleaved (step order): " + "  ".join("%s %.1f" % (n, t / a.reps) for n, t in zip(names, tot)), flush=True)
+    print("%s %dx%d %s: fwd %.1f (min %.1f)  fwd_sigma %.1f  fwd+save %.1f (min %.1f)  bwd %.1f (min %.1f) = chain %.1f + dW %.1f + reduce %.1f us"
           % (os.path.basename(os.environ.get("NERFHIP_LIB_PATH", "libnerfhip.so")), B, S, a.dtype, f_avg, f_min, so_avg, s_avg, s_min,
-             b_avg, b_min), flush=True)
+             b_avg, b_min, ph[0][0], ph[1][0], ph[2][0]), flush=True)
 
 
 if __name__ == "__main__":
