@@ -324,7 +324,12 @@ def main():
         eval_state["gr"] = GraphRenderer(models, emb, S, N, False, True)
 
     def eval_step():
-        return render_sharded(eval_state["gr"], eval_state["rays"], keys=("rgb_fine", "depth_fine"))
+        # one rank: finished chunks stream to pinned host memory while the next chunk replays (the image ends up where
+        # eval.py:123 needs it: on the host); N ranks: ray-sharded render, pixels all-gathered, rank 0 copies them out
+        if world == 1:
+            return eval_state["gr"].render_to_host(eval_state["rays"], keys=("rgb_fine", "depth_fine"))
+        res = render_sharded(eval_state["gr"], eval_state["rays"], keys=("rgb_fine", "depth_fine"))
+        return {k: v.cpu() for k, v in res.items()} if rank == 0 else res
 
     step = train_step if a.mode == "train" else (eval_step if a.mode == "eval" else render_step)
 
@@ -415,7 +420,7 @@ def main():
         out = {
             "metric": ("rays/sec (64+128 samples), full training step: render_rays fwd + MSE + bwd + grad all-reduce + Adam"
                        if a.mode == "train" else
-                       "rays/sec (64+128 samples), full-image inference (eval.py batched_inference, test_time, 32768-ray hipGraph chunks)"
+                       "rays/sec (64+128 samples), full-image inference incl. D2H of the pixels (eval.py batched_inference, test_time, 32768-ray hipGraph chunks)"
                        if a.mode == "eval" else
                        "rays/sec (64+128 samples), render_rays forward only (train-mode: coarse+fine rgb)"),
             "value": round(total_rays / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

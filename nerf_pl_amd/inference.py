@@ -105,6 +105,40 @@ class GraphRenderer:
         return {k: v[:n].clone() for k, v in self.out.items()}
 
     @torch.no_grad()
+    def render_to_host(self, rays, keys=("rgb_fine", "depth_fine")):
+        """Whole ray list -> PINNED host tensors, with the device-to-host copy of every finished chunk overlapped with
+        the replay of the next one (eval.py:123-131 does `.cpu()` on the whole image after the last chunk).
+
+        Compute stream: replay chunk i, then copy its outputs into slice i of a device-side image buffer (the graph's
+        static outputs are overwritten by the next replay; the slice is not) and record an event.  Copy stream: wait for
+        that event, DMA the slice into the pinned buffer.  Only the last chunk's copy is exposed."""
+        n = rays.shape[0]
+        dev = self.rays.device
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream()
+        img = {k: torch.empty((n,) + tuple(self.out[k].shape[1:]), device=dev, dtype=torch.float32) for k in keys}
+        host = {k: torch.empty(v.shape, dtype=torch.float32, pin_memory=True) for k, v in img.items()}
+        self._pack()
+        for i in range(0, n, self.chunk):
+            m = min(self.chunk, n - i)
+            self.rays[:m].copy_(rays[i:i + m])
+            if m < self.chunk:
+                self.rays[m:].copy_(rays[i + m - 1:i + m].expand(self.chunk - m, 8))
+            self.graph.replay()
+            for k in keys:
+                img[k][i:i + m].copy_(self.out[k][:m])
+            done = torch.cuda.Event()
+            done.record(cur)
+            self._copy_stream.wait_event(done)
+            with torch.cuda.stream(self._copy_stream):
+                for k in keys:
+                    host[k][i:i + m].copy_(img[k][i:i + m], non_blocking=True)
+        cur.wait_stream(self._copy_stream)
+        self._copy_stream.synchronize()
+        return host
+
+    @torch.no_grad()
     def __call__(self, rays):
         """Same result dict as batched_inference for a whole ray list."""
         results = defaultdict(list)
@@ -112,3 +146,25 @@ class GraphRenderer:
             for k, v in self.render_chunk(rays[i:i + self.chunk]).items():
                 results[k] += [v]
         return {k: (torch.cat(v, 0) if len(v) > 1 else v[0]) for k, v in results.items()}
+
+
+def save_image_outputs(results, h, w, dir_name, index, save_depth=False, depth_format="pfm"):
+    """The per-image tail of the reference's eval loop (eval.py:123-141): `results` holds host (or device) tensors
+    rgb_fine (h*w, 3) and depth_fine (h*w,); writes `{index:03d}.png` and, when asked, `depth_{index:03d}.pfm` or the raw
+    float32 bytes.  Returns the uint8 image (the reference collects them for the gif, eval.py:140,149)."""
+    import os
+
+    import numpy as np
+
+    from .imageio_min import depth_bytes, save_pfm, write_png
+    img_pred = results["rgb_fine"].reshape(h, w, 3).cpu().numpy()
+    if save_depth:
+        depth_pred = np.nan_to_num(results["depth_fine"].reshape(h, w).cpu().numpy())
+        if depth_format == "pfm":
+            save_pfm(os.path.join(dir_name, "depth_%03d.pfm" % index), depth_pred)
+        else:
+            with open(os.path.join(dir_name, "depth_%03d" % index), "wb") as f:
+                f.write(depth_bytes(depth_pred))
+    img_pred_ = (img_pred * 255).astype(np.uint8)
+    write_png(os.path.join(dir_name, "%03d.png" % index), img_pred_)
+    return img_pred_

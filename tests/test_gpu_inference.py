@@ -51,6 +51,29 @@ def test_graph_renderer_equals_eager_and_handles_tail(dev):
     assert not torch.equal(got2["rgb_fine"], got["rgb_fine"][:chunk])
 
 
+def test_render_to_host_overlapped_equals_device_path(dev, tmp_path):
+    """N3: the D2H-overlapped whole-image render (pinned host buffers filled chunk by chunk on a copy stream) returns the
+    same pixels as the device path, incl. the ragged tail chunk; and the eval loop's writers consume it."""
+    import numpy as np
+    from nerf_pl_amd import imageio_min as io
+    from nerf_pl_amd.inference import GraphRenderer, save_image_outputs
+    params = [O.make_params(21, 6.0, 0.3), O.make_params(22, 6.0, 0.3)]
+    ms, emb = build_models(params, dev, "bf16")
+    h, w, chunk = 40, 51, 512                                  # 2040 rays = 3 full chunks + a tail of 504
+    gr = GraphRenderer(ms, emb, 64, 128, False, True, chunk=chunk)
+    rays = O.make_rays(9, h * w, "blender").to(dev)
+    want = gr(rays)
+    for _ in range(2):                                         # twice: the copy stream / pinned buffers are reused
+        host = gr.render_to_host(rays, keys=("rgb_fine", "depth_fine", "opacity_fine"))
+        for k, v in host.items():
+            assert v.is_pinned() and not v.is_cuda
+            assert torch.equal(v, want[k].cpu()), k
+    img8 = save_image_outputs(host, h, w, str(tmp_path), 0, save_depth=True)
+    assert np.array_equal(io.read_png(str(tmp_path / "000.png")), img8)
+    d, _ = io.read_pfm(str(tmp_path / "depth_000.pfm"))
+    assert np.array_equal(d, want["depth_fine"].reshape(h, w).cpu().numpy())
+
+
 def test_full_chunk_properties_bf16(dev):
     """BASELINE-size chunk (32768 rays x (64+128)): size-independent properties instead of an oracle run:
     per-ray independence (any sub-batch renders identically), opacity in [0,1], rgb in [0,1] (white_back
