@@ -165,6 +165,13 @@ int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, cons
                            void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
                            int accumulate, int dtype, int phases, nerfhip_stream_t stream);
 
+/* d loss / d x of NeRF.forward on pre-embedded inputs (nerf.py:100-124 is differentiable w.r.t. x): from the dY slabs a
+ * nerfhip_mlp_bwd call left in `dys`,  gx[:, 0:63] = W_1^T dY_1 + W_5[:, :63]^T dY_5,  gx[:, 63:90] = W_dir[:, 256:]^T dY_dir.
+ * w_xyz1 / w_xyz5 / w_dir: the (out,in) fp32 weights of xyz_encoding_1, xyz_encoding_5, dir_encoding; gx (n, >= 90) with
+ * row stride gx_stride floats.  dtype NERFHIP_F32 | NERFHIP_BF16 (NERFHIP_BF16_F8 stores dY too coarsely: unsupported).   */
+int nerfhip_mlp_dx_embedded(const void* dys, int64_t n, const float* w_xyz1, const float* w_xyz5, const float* w_dir,
+                            float* gx, int64_t gx_stride, int dtype, nerfhip_stream_t stream);
+
 /* ---- N2. MSELoss.forward + psnr + backward seed  (losses.py:9-14, metrics.py:4-13, train.py:103-117) ----
  * rgb_coarse, rgb_fine (NULL when N_importance == 0), target: n = 3*rays floats each.
  * out3 = [loss, psnr of the fine (else coarse) image, its mse];  g_coarse / g_fine (NULL ok) receive

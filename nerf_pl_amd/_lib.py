@@ -58,6 +58,7 @@ SIGNATURES = {
     "nerfhip_mse_psnr": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "nerfhip_mlp_bwd_phases": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p],
+    "nerfhip_mlp_dx_embedded": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
     "nerfhip_adam_step": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                           ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64), _int, _c_void_p, _f32, _f32, _f32, _f32, _f32, _c_void_p],
     "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,

@@ -12,6 +12,8 @@
 //     accumulators in registers for the whole range, one partial slab per workgroup; mlp_bwd_reduce sums
 //     the slabs, un-permutes features and writes the (out,in) gradient tensors + biases.
 //     HBM-bound by construction: 2*256*256 FLOP per 2*256*2 B = 128 FLOP/B.
+#include <type_traits>
+
 #include "common.h"
 #include "mlp_layout.h"
 #include "f8_store.h"
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(WTable P, uint8_t* __r
         const BwdLayer ly = kBwdLayers[L];
         const int rel = g - start;
         const int f = rel / ppf(PREC), sub = rel % ppf(PREC);
-        const int ks = f / ly.nt, t = f % ly.nt;
+        const int ks = bwd_frag_slab(f, ly.nt, ly.nks), t = bwd_frag_tile(f, ly.nt, ly.nks);
         const int icol = ly.col0 + 32 * t + m;                     // input feature of W == output row of W^T
         float v[8];
 #pragma unroll
@@ -221,6 +223,23 @@ __device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_
     }
 }
 
+// dY pair store / block scale in the configured 8-bit format (f8_store.h: e5m2 by default, see NERFHIP_F8_DY_E5M2)
+__device__ __forceinline__ void save_dy_pair(int& pending, uint8_t* dy_tile, int pair, const bf16x8& s0, const bf16x8& s1, int sb, int lane) {
+#if NERFHIP_F8_DY_E5M2
+    save_pair_bf8(pending, dy_tile, pair, s0, s1, sb, lane);
+#else
+    save_pair_f8(pending, dy_tile, pair, s0, s1, sb, lane);
+#endif
+}
+__device__ __forceinline__ void save_dy_pair(int&, uint8_t*, int, const f32x8&, const f32x8&, int, int) {}    // (never used: fp8 storage is bf16-only)
+__device__ __forceinline__ int dy_block_scale(float lane_max) {
+#if NERFHIP_F8_DY_E5M2
+    return bf8_block_scale(lane_max);
+#else
+    return f8_block_scale(lane_max);
+#endif
+}
+
 // acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(pre-act), read as ONE 16-B
 // gate word per lane per layer (bit 8*ks+j, written by the forward's SAVE variant; mask_piece < 0 = no gate),
 // store as dY section, keep as next B operand.
@@ -260,6 +279,91 @@ __device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (
 #endif
         save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
     }
+}
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void bwd_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        bwd_static_for<B + 1, E>(f);
+    }
+}
+
+// ---- one backward layer, OUTPUT-TILE-MAJOR (NERFHIP_CHAIN_TILE_MAJOR): for each 32-row tile t of g_h(l-1) = W_l^T g_a(l):
+// 16-17 chained MFMAs over the input slabs, then the tile's epilogue — ReLU gate, bf16 pack into slabs 2t, 2t+1 of the OTHER
+// slab set (a layer reads one set while its tiles fill the other), stores — which overlaps the next tile's MFMAs (other
+// accumulator) instead of forming one ~420-instruction VALU block per layer during which the matrix pipe idles.
+// fp8 storage: like the forward, a layer stores its INPUT section (`gin`, live for the whole layer; `in_pairs` slab pairs
+// spread over the tiles, under the scale byte `in_sb` computed by ONE reduction at the end of the layer that produced it)
+// and returns the scale byte of its own output.
+template <int PREC, int L, int NT, int NKS, bool MASK, bool F8, int IN_PAIRS, typename Slab>
+__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char* smem_lane, const Slab (&gin)[NKS], Slab* out,
+                                                __amdgpu_buffer_rsrc_t acts, int gate_off, int mask_piece,
+                                                __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int in_sec,
+                                                int in_sb, int lane) {
+    constexpr int G0 = bwd_layer_start(L, PREC);
+    constexpr int PPF = ppf(PREC);
+    static_assert(kBwdLayers[L].nt == NT && kBwdLayers[L].nks == NKS, "bwd layer shape mismatch");
+    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
+    u32x4 gates = {0u, 0u, 0u, 0u};
+    if (MASK)
+        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
+    float mx = 0.0f;
+    f32x16 acc2[2];
+    // compile-time loop over the tiles: guarantees static register indexing of the slab arrays (a `#pragma unroll` loop of
+    // this size is not always fully unrolled, and one runtime index sends a whole 17-slab array to scratch memory)
+    bwd_static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        f32x16& acc = acc2[t & 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int g = G0 + (t * NKS + ks) * PPF;
+            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
+            if constexpr (PREC == NERFHIP_BF16) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gin[ks], acc, 0, 0, 0);
+            } else {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
+                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], gin[ks][j], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], gin[ks][4 + j], acc, 0, 0, 0);
+            }
+        }
+        if constexpr (F8 && PREC == NERFHIP_BF16) {                  // this tile's share of the INPUT section's pairs
+            if constexpr (IN_PAIRS > 0) {
+#pragma unroll
+                for (int q = 0; q < IN_PAIRS; ++q)
+                    if (q >= t * IN_PAIRS / NT && q < (t + 1) * IN_PAIRS / NT)        // folds: t is an unrolled constant
+                        save_dy_pair(st.pending, dy_tile, in_sec / 2 + q, gin[2 * q], gin[2 * q + 1], in_sb, lane);
+            }
+        }
+        // ---- epilogue of tile t ----
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gv = acc[8 * sl + j];
+                const int idx = 8 * (2 * t + sl) + j;      // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd_kernel.h run_layer)
+                const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)gates[idx >> 5], 31 - (idx & 31), 1);   // 0 | ~0
+                v[j] = MASK ? __uint_as_float(__float_as_uint(gv) & m) : gv;
+                if (F8) mx = fmaxf(mx, fabsf(v[j]));
+            }
+            mk_slab(out[2 * t + sl], v);
+            if constexpr (!F8) store_slab(st, dys, dy_sec + 2 * t + sl, out[2 * t + sl], lane);
+        }
+    });
+    if constexpr (F8 && PREC == NERFHIP_BF16) {
+        const int sb = dy_block_scale(mx);
+        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
+        return sb;
+    }
+    return 127;
 }
 
 template <int PREC, bool F8>
@@ -338,6 +442,30 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
         store_slab(st, dys, kDySigma + 1, zero_slab, lane);
     }
 
+#if NERFHIP_CHAIN_TILE_MAJOR
+    // scale bytes of the sections produced so far (F8); rgb / sigma pairs were stored above
+    Slab gd[8];
+    Slab ga[17], gb[17];
+    // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)  -> dY_dir in gd
+    Slab g_in0[1] = {g_rgb};
+    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, smem_lane, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
+                                                          -1, 127, lane);
+    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga   (F8: stores its input dY_dir)
+    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, smem_lane, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, kDyDir, sb, lane);
+    ga[16] = g_sig;
+    // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (F8: stores dY_feat)
+    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, smem_lane, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
+                                                       kDyFeat, sb, lane);
+#define NH_BWD(L, IN, OUT)                                                                                                  \
+    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, smem_lane, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
+                                                       mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), dy_h(11 - L), sb, lane);
+    NH_BWD(3, gb, ga) NH_BWD(4, ga, gb) NH_BWD(5, gb, ga) NH_BWD(6, ga, gb) NH_BWD(7, gb, ga) NH_BWD(8, ga, gb) NH_BWD(9, gb, ga)
+#undef NH_BWD
+    if constexpr (F8 && PREC == NERFHIP_BF16) {              // the last section (dY_1) has no consuming layer: flush it
+#pragma unroll
+        for (int q = 0; q < 8; ++q) save_dy_pair(st.pending, dy_tile, dy_h(1) / 2 + q, ga[2 * q], ga[2 * q + 1], sb, lane);
+    }
+#else
     // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)
     Slab gd[8];
     {
@@ -359,6 +487,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), gs, lane);
     NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
 #undef NH_BWD
+#endif
 }
 
 // ================================================================================================

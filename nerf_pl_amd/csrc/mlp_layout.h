@@ -188,6 +188,14 @@ constexpr BwdLayer kBwdLayers[kNumBwdLayers] = {
     {2, 8, 16, 0, 0},    // L3^T
     {1, 8, 16, 0, 0},    // L2^T : g_a2 -> g_h1
 };
+// Fragment order inside a backward-chain layer.  Output-tile-major (as the forward): fragment f = (tile f / nks, slab f % nks),
+// so that a tile's epilogue (gate, pack, store) overlaps the next tile's MFMAs; NERFHIP_CHAIN_TILE_MAJOR=0 restores the
+// slab-major order of round 1 (all tiles accumulated side by side, one epilogue block per layer).
+#ifndef NERFHIP_CHAIN_TILE_MAJOR
+#define NERFHIP_CHAIN_TILE_MAJOR 1
+#endif
+NH_HD constexpr int bwd_frag_tile(int f, int nt, int nks) { return NERFHIP_CHAIN_TILE_MAJOR ? f / nks : f % nt; }
+NH_HD constexpr int bwd_frag_slab(int f, int nt, int nks) { return NERFHIP_CHAIN_TILE_MAJOR ? f % nks : f / nt; }
 NH_HD constexpr int bwd_layer_pieces(int L, int prec) { return kBwdLayers[L].nks * kBwdLayers[L].nt * ppf(prec); }
 NH_HD constexpr int bwd_layer_start(int L, int prec) {
     int g = 0;

@@ -3,16 +3,17 @@
 Training forward = the same fused kernel with `save_acts` (every layer's B-operand slabs written once,
 in register order); backward = nerfhip_mlp_bwd.  Gradients flow to the 24 parameter tensors only:
 the reference detaches the importance samples (rendering.py:226) and its rays carry no grad, so
-d/d(rays, z) is never needed; d/dx of pre-embedded inputs is not implemented (raises)."""
+d/d(rays, z) is never needed; d/dx of pre-embedded inputs (NeRF.forward called directly) comes from
+nerfhip_mlp_dx_embedded."""
 import torch
 
 from .. import ops
 
 
-def _param_grads(model, out, acts, dtype, g_out):
+def _param_grads(model, out, acts, dtype, g_out, workspace=None):
     """nerfhip_mlp_bwd (chain + dW + reduce kernels) -> gradients in `flat_params()` order."""
     packed_bwd = model.packed_weights_bwd(dtype)
-    gw, gb, flat = ops.mlp_bwd(g_out, out, packed_bwd, acts, dtype)
+    gw, gb, flat = ops.mlp_bwd(g_out, out, packed_bwd, acts, dtype, workspace=workspace)
     model._flat_grad = flat          # contiguous view of this step's gradients (parallel.GradSync / FlatAdam use it)
     hook = getattr(model, "_grad_ready_hook", None)
     if hook is not None:             # parallel.GradSync: start this model's all-reduce while autograd keeps going
@@ -59,13 +60,16 @@ class _MLPEmbedded(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("nerf_pl_amd: gradient w.r.t. pre-embedded NeRF inputs is not implemented "
-                                      "(never needed by the reference: rays carry no grad)")
         (out,) = ctx.saved_tensors
-        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out)
+        ws = {} if ctx.needs_input_grad[1] else None
+        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, workspace=ws)
         ctx.acts = None
-        return (None, None) + tuple(grads)
+        gx = None
+        if ctx.needs_input_grad[1]:          # nerf.py:100-124 is differentiable w.r.t. x: dx from the chain's dY slabs
+            m = ctx.model
+            gx = ops.mlp_dx_embedded(ws["dys"], out.shape[0], m.xyz_encoding_1[0].weight, m.xyz_encoding_5[0].weight,
+                                     m.dir_encoding[0].weight, ctx.dtype)
+        return (None, gx) + tuple(grads)
 
 
 def mlp_rays(model, rays, z, sigma_only):

@@ -387,3 +387,17 @@ def mlp_bwd(g_out, out, packed_bwd, acts, dtype, shapes=PARAM_SHAPES, phases=7, 
     check(lib.nerfhip_mlp_bwd_phases(ptr(g_out), ptr(out), n, ptr(packed_bwd), ptr(acts), ptr(dys), ptr(ws), gwp, gbp, 0, code,
                                      int(phases), stream_ptr()), "nerfhip_mlp_bwd")
     return gw, gb, flat
+
+
+@device_guard
+def mlp_dx_embedded(dys, n, w_xyz1, w_xyz5, w_dir, dtype):
+    """dL/dx (n, 90) of NeRF.forward on pre-embedded inputs from the dY slabs of the preceding mlp_bwd call."""
+    code = mlp_dtype_code(dtype)
+    if code == BF16_F8:
+        raise NotImplementedError("gradient w.r.t. pre-embedded NeRF inputs needs mlp_dtype 'bf16' or 'fp32' "
+                                  "('bf16_f8' keeps dY only as e5m2)")
+    require_gpu(w_xyz1, w_xyz5, w_dir)
+    gx = torch.empty(n, 90, device=dys.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_mlp_dx_embedded(ptr(dys), n, ptr(_c(w_xyz1.detach())), ptr(_c(w_xyz5.detach())), ptr(_c(w_dir.detach())),
+                                              ptr(gx), 90, code, stream_ptr()), "nerfhip_mlp_dx_embedded")
+    return gx

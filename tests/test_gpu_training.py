@@ -341,6 +341,43 @@ def test_sigma_only_forward_is_differentiable(dev):
             assert (prm.grad.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7, name
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gradient_wrt_preembedded_inputs(dev, dtype):
+    """NeRF.forward is differentiable w.r.t. its (pre-embedded) input like the reference module (nerf.py:100-124):
+    nerfhip_mlp_dx_embedded against autograd through the oracle; the fp8-storage mode refuses (its dY is e5m2)."""
+    n = 700
+    g = torch.Generator().manual_seed(5)
+    p = O.make_params(21, 3.0, 0.1)
+    pts = torch.rand(n, 3, generator=g) * 4 - 2
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    x = torch.cat([O.posenc(pts, 10), O.posenc(dirs, 4)], 1)
+    g_out = torch.randn(n, 4, generator=g)
+    x0 = x.clone().requires_grad_(True)
+    (O.mlp_forward(p, x0) * g_out).sum().backward()
+    (m,), _ = build_models([p], dev, dtype)
+    x1 = x.clone().to(dev).requires_grad_(True)
+    (m(x1) * g_out.to(dev)).sum().backward()
+    assert x1.grad is not None and x1.grad.shape == (n, 90)
+    ref, got = x0.grad, x1.grad.cpu()
+    if dtype == "fp32":
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), (got - ref).abs().max().item()
+    else:
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        assert cos >= 0.99, cos
+    assert all(q.grad is not None for q in m.parameters())           # parameter gradients still flow
+    # sigma-only forward: d sigma / d x_xyz
+    x2 = x[:, :63].clone().requires_grad_(True)
+    (O.mlp_forward(p, x2, sigma_only=True) * g_out[:, 3:]).sum().backward()
+    x3 = x[:, :63].clone().to(dev).requires_grad_(True)
+    (m(x3, sigma_only=True) * g_out[:, 3:].to(dev)).sum().backward()
+    if dtype == "fp32":
+        assert (x3.grad.cpu() - x2.grad).abs().max().item() <= 2e-4 * x2.grad.abs().max().item()
+    (m8,), _ = build_models([p], dev, "bf16_f8")
+    x4 = x.clone().to(dev).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        (m8(x4) * g_out.to(dev)).sum().backward()
+
+
 def test_empty_batch_gradients_are_zero(dev):
     """n == 0 launches nothing: the 24 gradients of an empty batch must be zeros, not uninitialised memory."""
     (m,), _ = build_models([O.make_params(5)], dev, "bf16")
