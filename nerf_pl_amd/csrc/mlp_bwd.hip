@@ -980,6 +980,10 @@ static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
     int off = 0;
     for (int j = 0; j < kNumDwJobs; ++j) {
         int64_t ns = NERFHIP_DW_WGS / kNumDwJobs;
+#ifndef NERFHIP_DW_MIN_ITERS
+#define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
+#endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
+        if (NERFHIP_DW_MIN_ITERS > 0 && ns > tiles / NERFHIP_DW_MIN_ITERS) ns = tiles / NERFHIP_DW_MIN_ITERS;
         if (ns > tiles) ns = tiles;
         if (ns < 1) ns = 1;
         if (jt) {
