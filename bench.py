@@ -160,10 +160,28 @@ def synth_store(seed, dev, n_img=20, hw=200):
     return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.3, 2.0, 6.0)
 
 
-def event_time(fn, reps, warm=3):
-    """Average / min microseconds per call of `fn` by HIP events on torch's current stream (where libnerfhip launches)."""
+def event_time(fn, reps, warm=3, graph=False):
+    """Average / min microseconds per call of `fn` by HIP events on torch's current stream (where libnerfhip launches).
+    graph=True: `reps` calls are captured into one hipGraph and the replay is timed — for kernels of a few tens of
+    microseconds, whose eager issue (ctypes + torch.empty) is slower than the kernel itself."""
     for _ in range(warm):
         fn()
+    if graph:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        us = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3 / reps)
+        return sum(us) / len(us), min(us)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
     for i in range(reps):
@@ -197,7 +215,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
         ops.mlp_bwd(g_out, raw, pb, acts, dtype, workspace=ws)
         act_b, dy_b = acts.numel(), ws["dys"].numel()
         gate_b = (P + 31) // 32 * 9 * 1024
-        ws_b = int(lib.nerfhip_mlp_dw_workspace_bytes(P, code))
+        # split-K partials the reduce kernel reads: per split 592 used (out-tile, x-tile) blocks of 4 KiB over the 12 jobs
+        ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 12 * 592 * 4096
         rows = [
             ("mlp_fwd_kernel<save>", lambda: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
              FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point"),
@@ -209,7 +228,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
              0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written"),
         ]
         for name, fn, flops, nbytes, what in rows:
-            avg, mn = event_time(fn, 12)
+            avg, mn = event_time(fn, 12, graph=True)
             tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
             fm, fh = tf / PEAK_TFLOPS[dtype], gbs / PEAK_HBM_GBS
             key = "%s|%s|%d" % (name, dtype, P)

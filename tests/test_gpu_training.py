@@ -109,7 +109,9 @@ def test_training_grads_fp32_vs_reference_golden(golden, dev, prefix):
     for name, prm in full:
         ref = golden[f"{prefix}_full_{name}"]
         err = (prm.grad.cpu() - ref).abs().max().item()
-        assert err <= 2e-4 * ref.abs().max().item() + 1e-9, (prefix, name, err, ref.abs().max().item())
+        # 2e-4 of the tensor's max |grad|, with an absolute floor of 5e-9: the smallest tensors (first-layer bias, max 3e-7)
+        # are cancelling sums of ~6000 terms of 1e-6, whose fp32 accumulation error alone is ~2e-9 in either implementation
+        assert err <= 2e-4 * ref.abs().max().item() + 5e-9, (prefix, name, err, ref.abs().max().item())
 
 
 def test_training_step_loss_decreases_bf16(dev):
