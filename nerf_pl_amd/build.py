@@ -31,7 +31,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 EXTRA = [f for f in os.environ.get("NERFHIP_EXTRA_FLAGS", "").split() if f]     # A/B kernel builds (-DNERFHIP_...=)
 
 # (source, object suffix, extra -D flags): sources compiled more than once
-MULTI = {"mlp_fwd_variant.hip": [("_p%dm%dv%d" % (p, m, v), ["-DNH_PREC=%d" % p, "-DNH_MODE=%d" % m, "-DNH_VARIANT=%d" % v])
+# The fp8-storage activation-saving forward (variant 3) sits exactly at the 256-register limit of its 2-waves-per-SIMD
+# launch bounds: hipcc's default scheduling strategy spills 25-37 VGPRs there, `max-memory-clause` 2 (the other variants do not
+# spill under either).  NERFHIP_V3_SCHED= (empty) builds it with the default strategy (A/B).
+V3_SCHED = os.environ.get("NERFHIP_V3_SCHED", "max-memory-clause")
+MULTI = {"mlp_fwd_variant.hip": [("_p%dm%dv%d" % (p, m, v), ["-DNH_PREC=%d" % p, "-DNH_MODE=%d" % m, "-DNH_VARIANT=%d" % v]
+                                  + (["-mllvm", "-amdgpu-sched-strategy=" + V3_SCHED] if (v == 3 and V3_SCHED) else []))
                                  for p in (0, 1) for m in (0, 1) for v in (0, 1, 2, 3) if not (v == 3 and p == 0)]}
 
 

@@ -204,6 +204,19 @@ __device__ __forceinline__ float slab_absmax(const bf16x8& s) {
     return m;
 }
 
+// The lane id, recomputed (v_mbcnt): a value the register allocator can drop and recreate instead of keeping the prologue's
+// copy — and everything derived from it — live (at the 256-register limit: spilled to scratch) across the whole network.
+__device__ __forceinline__ int fresh_lane() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// the same as opaque inline asm (the builtins are CSE'd back into one long-lived value): for the single use after the last
+// layer; inside the layers an asm statement would act as a scheduling barrier (measured: +30 spilled registers)
+__device__ __forceinline__ int fresh_lane_opaque() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // ---- one layer, OUTPUT-TILE-MAJOR: for each 32-row output tile t: acc = bias; acc += W_frag(t,ks) * B[ks] over all
 // input slabs ks; then that tile's epilogue (activation, pack to the next layer's B slabs 2t and 2t+1, ReLU gate
 // bits, activation stores) runs while the matrix pipe already works on tile t+1 (other accumulator).  The
@@ -222,6 +235,7 @@ __device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st,
                                          uint8_t* rsrc, int act_sec, int gate_piece, int lane, int in_sec = -1, int in_sb = 127) {
     constexpr bool SAVE = SV != 0, F8 = SV == 2;
     static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
+    lane = SAVE ? fresh_lane() : lane;
     constexpr Layer ly = kLayers[L];
     static_assert(ly.nt == NT, "tile count mismatch");
     constexpr int G0 = layer_start(L, PREC);
@@ -258,6 +272,9 @@ __device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st,
     Slab a[D];
     static_for<0, D>([&](auto ic) { load_frag(ic, a[decltype(ic)::value]); });
 
+#ifndef NERFHIP_GATE_DWORD_STORES
+#define NERFHIP_GATE_DWORD_STORES 1   // store each 32-bit gate word as soon as its two tiles are done (one live register
+#endif                                // instead of four: the activation-saving kernels run at the 256-register limit)
     f32x16 acc[2];
     unsigned gw[4] = {0u, 0u, 0u, 0u};
     float mx = 0.0f;                                   // F8: this lane's max |output| of the layer
@@ -275,10 +292,11 @@ __device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st,
                 for (int k = 0; k < 4; ++k) c[4 * q + k] = b[k];
             }
         }
-        // B operand: an input-encoding slab (parked in this wave's LDS stash, enc_lds = base + lane*sizeof(Slab))
+        // B operand: an input-encoding slab (parked in this wave's LDS stash)
         // or a slab of the previous layer's activations (registers)
         Slab bs;
-        if constexpr (ks < ly.enc_slabs) bs = *reinterpret_cast<const Slab*>(enc_lds + ks * 64 * (int)sizeof(Slab));
+        if constexpr (ks < ly.enc_slabs)      // (enc_lds = the wave's stash base; the lane offset is added here, from the fresh lane id)
+            bs = *reinterpret_cast<const Slab*>(enc_lds + lane * (int)sizeof(Slab) + ks * 64 * (int)sizeof(Slab));
         else bs = chain[ks - ly.enc_slabs];
         if constexpr (PREC == NERFHIP_BF16) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % D], bs, c, 0, 0, 0);
@@ -333,13 +351,19 @@ __device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st,
                     make_slab(out[2 * t + sl], v);
                 }
                 if constexpr (SAVE && !F8) save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
+                if constexpr (SAVE && RELU && NERFHIP_GATE_DWORD_STORES && (t & 1) == 1) {
+                    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+                        rsrc + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) + gate_piece * kPieceBytes, 0, kPieceBytes, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b32(gw[t >> 1], grs, (unsigned)lane * 16u + 4u * (t >> 1), 0, 0);
+                    st.pending += 1;
+                }
             }
 #if NERFHIP_TILE_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from stretching live ranges across tiles
 #endif
         }
     });
-    if constexpr (SAVE && RELU && NT != 1) {
+    if constexpr (SAVE && RELU && NT != 1 && !NERFHIP_GATE_DWORD_STORES) {
         u32x4 g;
         g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
         save_gates(st, rsrc, F8 ? f8_act_gate_off() : act_mask_off(PREC), gate_piece, g, lane);
@@ -500,13 +524,13 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
         save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
     }
-    char* enc_x = ring + kSlots * kChunkBytes + NW * kPieceBytes + wave * kEncStash + lane * (int)sizeof(Slab);
+    char* enc_x = ring + kSlots * kChunkBytes + NW * kPieceBytes + wave * kEncStash;      // wave-uniform stash bases
     char* enc_d = enc_x + kXyzSlabs * 64 * (int)sizeof(Slab);
 #pragma unroll
-    for (int k = 0; k < kXyzSlabs; ++k) *reinterpret_cast<Slab*>(enc_x + k * 64 * (int)sizeof(Slab)) = encx[k];
+    for (int k = 0; k < kXyzSlabs; ++k) *reinterpret_cast<Slab*>(enc_x + lane * (int)sizeof(Slab) + k * 64 * (int)sizeof(Slab)) = encx[k];
     if (!SIGMA_ONLY) {
 #pragma unroll
-        for (int k = 0; k < kDirSlabs; ++k) *reinterpret_cast<Slab*>(enc_d + k * 64 * (int)sizeof(Slab)) = encd[k];
+        for (int k = 0; k < kDirSlabs; ++k) *reinterpret_cast<Slab*>(enc_d + lane * (int)sizeof(Slab) + k * 64 * (int)sizeof(Slab)) = encd[k];
     }
     // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
     Slab ha[16], hb[16];
@@ -530,7 +554,11 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     const float sigma = raw[0];                              // row 0 lives in reg 0 of the h=0 lanes
 
     if (SIGMA_ONLY) {
-        if (valid && h == 0) out[p] = sigma;                // (n,1)   nerf.py:112-114
+        // (output index from a recomputed lane id: otherwise the 64-bit address computed in the prologue is kept live —
+        //  i.e. spilled to scratch — across the whole network)
+        const int lane_o = fresh_lane_opaque();
+        const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
+        if (po < n && (lane_o >> 5) == 0) out[po] = sigma;  // (n,1)   nerf.py:112-114
         return;
     } else {
         // xyz_encoding_final: no activation (nerf.py:116) -> ha   (F8: stores its input h8)
@@ -541,13 +569,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
                                                    kMaskPieceT, lane, kActFeat, sb);
         run_layer<PREC, 11, NCH, 1, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
                                                tile_base, 0, 0, lane, kActT, sb);                       // (F8: stores its input t)
-        if (valid && h == 0) {
+        const int lane_o = fresh_lane_opaque();
+        const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
+        if (po < n && (lane_o >> 5) == 0) {
             float4 o;
             o.x = 1.0f / (1.0f + expf(-raw[0]));            // sigmoid   nerf.py:79-81
             o.y = 1.0f / (1.0f + expf(-raw[1]));
             o.z = 1.0f / (1.0f + expf(-raw[2]));
             o.w = sigma;                                     // cat([rgb, sigma])   nerf.py:122
-            reinterpret_cast<float4*>(out)[p] = o;
+            reinterpret_cast<float4*>(out)[po] = o;
         }
     }
 }
