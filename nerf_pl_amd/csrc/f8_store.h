@@ -11,6 +11,10 @@
 #define NERFHIP_F8EXP 0         // timing experiments only (results invalid): 1 = convert but do not store, 2 = store without converting
 #endif
 
+#ifndef NERFHIP_STORE_SLACK
+#define NERFHIP_STORE_SLACK 1   // weight-ring boundaries let the stores of the last TWO chunk intervals stay in flight (0: one)
+#endif
+
 namespace nerfhip {
 using namespace mlp;
 

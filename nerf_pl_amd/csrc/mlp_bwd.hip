@@ -143,6 +143,7 @@ struct BwdStream {
     unsigned lds_base;
     int wave;
     int pending;   // stores issued since the last boundary (constant-folded; see mlp_fwd.hip)
+    int pending_prev;
 
     __device__ __forceinline__ void issue_chunk(int c) const {
 #pragma unroll
@@ -153,7 +154,11 @@ struct BwdStream {
         }
     }
     __device__ __forceinline__ void boundary(int c) {
-        const int n = (c + 1 < NCH ? LPW : 0) + pending;
+        // chunk c's DMAs were issued at boundary c-2: younger than them are the stores of the interval before the previous
+        // boundary (pending_prev), chunk c+1's DMAs and the stores since the previous boundary => stores get two chunk
+        // intervals to retire before a boundary waits for them
+        const int n = (c + 1 < NCH ? LPW : 0) + pending + (NERFHIP_STORE_SLACK ? pending_prev : 0);
+        pending_prev = pending;
         pending = 0;
 #define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {
@@ -401,6 +406,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     st.lds_base = (unsigned)(uintptr_t)ring;
     st.wave = wave;
     st.pending = 0;
+    st.pending_prev = 0;
     st.issue_chunk(0);
     st.issue_chunk(1);
     const char* smem_lane = ring + lane * 16;

@@ -95,6 +95,7 @@ struct WeightStream {
     int wave;                // wave index in the workgroup (SGPR)
     int pending;             // vector-memory STORE instructions issued since the last boundary (SAVE variant).
                              // Straight-line code: the optimiser folds this to a constant at every boundary.
+    int pending_prev;        // ... and in the interval before that
 
     __device__ __forceinline__ void issue_piece(int c, int k) const {      // k-th of this wave's LPW pieces of chunk c
         const int piece = wave + k * NW;
@@ -129,7 +130,10 @@ struct WeightStream {
         // LPW DMAs of chunk c+1 plus the `pending` activation stores issued since the previous boundary
         // (older stores are waited for as well — harmless).  Under-counting only over-waits.
         if constexpr (COUNT_STORES) {
-            const int n = (c + 1 < NCH ? LPW : 0) + pending;
+            // chunk c's DMAs were issued at boundary c-2; younger than them are the stores of the interval before the previous
+            // boundary (pending_prev), chunk c+1's DMAs and the stores since the previous boundary (pending)
+            const int n = (c + 1 < NCH ? LPW : 0) + pending + (NERFHIP_STORE_SLACK ? pending_prev : 0);
+            pending_prev = pending;
             pending = 0;
             wait_barrier(n);
         } else if (c + 1 < NCH) {
@@ -377,6 +381,239 @@ __device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st,
     return 127;
 }
 
+// ====================================================================================================================
+// Software-pipelined layer (NERFHIP_PIPE): the epilogue of output tile t (activation, pack into the next layer's B slabs)
+// is EMITTED, in eight 2-value pieces, between the first MFMAs of tile t+1 — which accumulates into the other accumulator —
+// and the bias of tile t+2 is read into the freed accumulator a few MFMAs later; a layer's last tile is finished inside
+// the next layer's first tile (its slabs 2(NT-1), 2(NT-1)+1 are not consumed before slab step enc_slabs + 2(NT-1)).  A
+// `sched_barrier` after every MFMA step pins that order.  Before: hipcc kept the tile epilogue (s_nop + ~50 VALU + 4 bias
+// reads + wait) in one block BETWEEN tiles and merged the two accumulators into one register set, so every 16 MFMAs each
+// wave — and, the waves of a SIMD being chunk-synchronised by the ring barriers, the whole SIMD — left the matrix pipe
+// idle for ~400 cycles.
+// Biases are read from a workgroup-shared 12 KiB LDS image filled once in the prologue (the in-stream bias pieces still
+// travel through the ring; they are not read), A fragments and encoding operands are prefetched D steps ahead ACROSS
+// layer boundaries (fragment slots are numbered over the whole network).
+#ifndef NERFHIP_PIPE
+#define NERFHIP_PIPE 1
+#endif
+typedef __attribute__((ext_vector_type(2))) short nh_s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 nh_bf16x2;
+
+NH_HD constexpr int layer_frags(int L) { return L < 0 ? 0 : kLayers[L].nt * (kLayers[L].enc_slabs + kLayers[L].chain_slabs); }
+NH_HD constexpr int frag_base(int L) {            // fragments before layer L (execution order)
+    int n = 0;
+    for (int i = 0; i < L; ++i) n += layer_frags(i);
+    return n;
+}
+// pending-epilogue kinds
+constexpr int PK_NONE = 0, PK_RELU = 1, PK_LINEAR = 2, PK_SIGMA = 3;
+// per-layer facts (execution-order index, kLayers)
+NH_HD constexpr bool layer_relu(int L) { return L <= 7 || L == 10; }
+NH_HD constexpr int pend_kind(int PL) {
+    return PL < 0 ? PK_NONE : (PL == kSigmaLayer ? PK_SIGMA : (layer_relu(PL) ? PK_RELU : PK_LINEAR));
+}
+// saved-activation section / gate piece of a layer's OUTPUT; section a layer stores in the fp8 mode (its chain INPUT)
+NH_HD constexpr int layer_out_sec(int L) { return L <= 7 ? act_h(L + 1) : (L == 9 ? kActFeat : (L == 10 ? kActT : -1)); }
+NH_HD constexpr int layer_gate_piece(int L) { return L <= 7 ? mask_piece_h(L + 1) : (L == 10 ? kMaskPieceT : -1); }
+NH_HD constexpr int layer_in_sec(int L) {
+    return (L >= 1 && L <= 7) ? act_h(L) : (L == 9 ? act_h(8) : (L == 10 ? kActFeat : (L == 11 ? kActT : -1)));
+}
+
+#ifndef NERFHIP_PF_SAVE
+#define NERFHIP_PF_SAVE 2
+#endif
+template <int PREC, int SV, typename Slab>
+struct PipeCtx {
+    static constexpr int D = (PREC != NERFHIP_BF16) ? 1 : (SV != 0 ? NERFHIP_PF_SAVE : NERFHIP_PF2);
+    Slab a[D];        // A-fragment ring
+    Slab bq[D];       // encoding-operand ring (slots of fragments whose B operand is an encoding slab)
+    f32x16 acc[2];
+    const char* smem_lane;     // ring + lane*16
+    const char* bias_lane;     // bias image + (lane>>5)*16
+    const char* enc_x;         // this lane's slot of the wave's encoding stash
+    const char* enc_d;
+    // activation-saving variants
+    uint8_t* tile;             // this wave's saved-activation block
+    unsigned gw[4];            // ReLU gate words of the layer in flight
+    unsigned mx;               // fp8 storage: this lane's max |output| of the layer in flight, as two bf16 halves (even / odd values)
+    int sb;                    // fp8 storage: e8m0 scale byte of the most recently finished section
+};
+
+// one 2-value piece p (0..7) of the epilogue of the finished tile `c` (tile pt of layer PL):
+// -> dword (p & 3) of slab 2*pt + (p >> 2) of `po`; SAVE: gate bits, slab / gate-word stores, running maximum
+template <int PREC, int SV, int PL, typename Ctx, typename St, typename Slab>
+__device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab* po, int pt, int p) {
+    constexpr bool RELU = layer_relu(PL), SAVE = SV != 0, F8 = SV == 2;
+    Slab& o = po[2 * pt + (p >> 2)];
+    unsigned& gw = cx.gw[(pt >> 1) & 3];
+    if constexpr (PREC == NERFHIP_BF16) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2v;
+        typedef __attribute__((ext_vector_type(2))) unsigned short u16x2v;
+        const f32x2v xv = {c[2 * p], c[2 * p + 1]};
+        nh_bf16x2 pk = __builtin_convertvector(xv, nh_bf16x2);       // one v_cvt_pk_bf16_f32
+        if (RELU) {     // relu after rounding == rounding after relu; packed signed-integer max with 0 clears negative halves
+            nh_s16x2 sv = __builtin_bit_cast(nh_s16x2, pk);
+            const nh_s16x2 z = {0, 0};
+            sv = __builtin_elementwise_max(sv, z);
+            pk = __builtin_bit_cast(nh_bf16x2, sv);
+        }
+        o[2 * (p & 3)] = pk[0];
+        o[2 * (p & 3) + 1] = pk[1];
+        if (SAVE && RELU) {
+            // gate of value idx = 8*(2pt+sl) + j -> word idx>>5, bit 31-(idx&31) (values arrive in idx order): the halves are
+            // >= 0 after the ReLU, so bit 15 of (half + 0x7fff) is [half > 0]
+            const u16x2v k = {0x7fff, 0x7fff};
+            const unsigned tt = __builtin_bit_cast(unsigned, (u16x2v)(__builtin_bit_cast(u16x2v, pk) + k));
+            gw = (gw << 1) | ((tt >> 15) & 1u);
+            gw = __builtin_amdgcn_alignbit(gw, tt, 31);
+        }
+        if (F8) {       // running maximum of the STORED magnitudes: non-negative bf16 halves order like unsigned integers
+            unsigned d = __builtin_bit_cast(unsigned, pk);
+            if (!RELU) d &= 0x7fff7fffu;
+            cx.mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, cx.mx), __builtin_bit_cast(u16x2v, d)));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float x = c[2 * p + k];
+            // max(bits, 0) as signed integers == relu for every non-NaN float (negative floats are negative integers)
+            const float r = RELU ? __int_as_float(max(__float_as_int(x), 0)) : x;
+            o[2 * (p & 3) + k] = r;
+            if (SAVE && RELU) gw = __builtin_amdgcn_alignbit(gw, __float_as_uint(r) + 0x7fffffffu, 31);
+        }
+    }
+    if constexpr (SAVE) {
+        const int lane = fresh_lane();
+        if (!F8 && (p & 3) == 3) save_slabs(st, cx.tile, layer_out_sec(PL) + 2 * pt + (p >> 2), &o, 1, lane);
+        if (RELU && p == 7 && (pt & 1)) {
+            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+                cx.tile + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) + layer_gate_piece(PL) * kPieceBytes, 0, kPieceBytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(gw, grs, (unsigned)lane * 16u + 4u * (unsigned)(pt >> 1), 0, 0);
+            st.pending += 1;
+        }
+    }
+}
+
+// fragment j of layer L -> ring slot; issues the LDS reads (and the chunk-boundary protocol of its pieces)
+template <int PREC, int NCH, int L, int J, typename Ctx, typename St>
+__device__ __forceinline__ void pipe_prefetch(Ctx& cx, St& st) {
+    using Slab = typename PrecTraits<PREC>::Slab;
+    constexpr Layer ly = kLayers[L];
+    constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
+    constexpr int G0 = layer_start(L, PREC), PPF = ppf(PREC);
+    constexpr int slot = (frag_base(L) + J) % Ctx::D;
+    constexpr int g = G0 + 1 + J * PPF;
+    auto piece_off = [](int gg) { return ((gg / kChunkPieces) % kSlots) * kChunkBytes + (gg % kChunkPieces) * kPieceBytes; };
+    if constexpr (J == 0) st.template at_piece<G0>();        // the layer's in-stream bias piece (not read)
+    st.template at_piece<g>();
+    if constexpr (PREC == NERFHIP_BF16) {
+        cx.a[slot] = *reinterpret_cast<const bf16x8*>(cx.smem_lane + piece_off(g));
+    } else {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cx.smem_lane + piece_off(g));
+        st.template at_piece<g + 1>();
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(cx.smem_lane + piece_off(g + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cx.a[slot][j] = a0[j]; cx.a[slot][4 + j] = a1[j]; }
+    }
+    constexpr int ks = frag_slab(J, ly.nt, NKS);
+    if constexpr (ks < ly.enc_slabs) {
+        const char* e = (ly.kind == IN_DIR_CHAIN) ? cx.enc_d : cx.enc_x;
+        cx.bq[slot] = *reinterpret_cast<const Slab*>(e + ks * 64 * (int)sizeof(Slab));
+    }
+}
+template <int L, int T, typename Ctx>
+__device__ __forceinline__ void pipe_bias(Ctx& cx, f32x16& c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(cx.bias_lane + L * kPieceBytes + (32 * T + 8 * q) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[4 * q + k] = b[k];
+    }
+}
+
+// L: this layer; NL: next layer in execution order (-1: none); PAR0: accumulator parity of tile 0; PL: the layer whose last
+// tile is still pending (-1: none), its epilogue goes to `pout` (sigma head: c[0] -> *psig).  On entry acc[PAR0] holds the
+// bias of tile 0 and the first D fragments are in flight; on exit the same holds for layer NL, and the epilogue of this layer's
+// last tile is pending in acc[(PAR0 + NT - 1) & 1].
+// Activation-saving variants (SV): the pieces also build the gate words and store slabs / gate words as they complete; in the
+// fp8 mode a layer stores its INPUT section pair by pair a few steps after the pieces of each tile, under the scale byte that
+// ONE wave reduction — placed right after the pending layer's last piece — produced.
+template <int PREC, int NCH, int SV, int L, int NL, int PAR0, int PL, typename Ctx, typename St, typename Slab>
+__device__ __forceinline__ void run_layer_pipe(Ctx& cx, St& st, const Slab* chain, Slab* out, Slab* pout, float* psig) {
+    constexpr Layer ly = kLayers[L];
+    constexpr int NT = ly.nt, NKS = ly.enc_slabs + ly.chain_slabs, N = NT * NKS, D = Ctx::D;
+    constexpr int NN = layer_frags(NL);
+    constexpr int PK = pend_kind(PL), PT = kLayers[PL >= 0 ? PL : 0].nt - 1;
+    constexpr bool F8 = SV == 2;
+    static_assert(!NERFHIP_TILE_PAIRS, "the pipelined layer assumes tile-major fragment order");
+
+    static_for<0, N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = i / NKS, ks = i % NKS;
+        constexpr int slot = (frag_base(L) + i) % D;
+        f32x16& c = cx.acc[(PAR0 + t) & 1];
+        f32x16& cp = cx.acc[(PAR0 + t + 1) & 1];          // the previous tile's accumulator (pending epilogue), then tile t+1's
+
+        Slab bs;
+        if constexpr (ks < ly.enc_slabs) bs = cx.bq[slot];
+        else bs = chain[ks - ly.enc_slabs];
+        if constexpr (PREC == NERFHIP_BF16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cx.a[slot], bs, c, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.a[slot][j], bs[j], c, 0, 0, 0);
+        }
+        // refill the slot: fragment i+D of this layer, or of the next one
+        if constexpr (i + D < N) pipe_prefetch<PREC, NCH, L, i + D>(cx, st);
+        else if constexpr (NL >= 0 && i + D - N < NN) pipe_prefetch<PREC, NCH, (NL >= 0 ? NL : 0), i + D - N>(cx, st);
+
+        // ---- pending epilogue of the previous tile, spread over steps ks0 .. ks0 + span - 1 ----
+        constexpr int kind = (t == 0) ? PK : (layer_relu(L) ? PK_RELU : PK_LINEAR);
+        constexpr int pl = (t == 0) ? (PL >= 0 ? PL : 0) : L;      // layer / tile the pending accumulator belongs to
+        constexpr int pt = (t == 0) ? PT : t - 1;
+        // first slab step that consumes what the pending epilogue produces (previous layer's slabs 2PT, 2PT+1)
+        constexpr int ks1 = (t == 0 && (PK == PK_RELU || PK == PK_LINEAR)) ? ly.enc_slabs + 2 * PT : NKS;
+        // first step: 2 where there is room (the MFMA-result hazard window has passed; at step 1 hipcc pads with s_nop)
+        constexpr int ks0 = (ks1 - 2 >= 8) ? 2 : 1;
+        constexpr int span = (ks1 - ks0 < 8) ? ks1 - ks0 : 8;
+        static_assert(span >= 1, "no room for the pending epilogue");
+        if constexpr (kind == PK_SIGMA) {
+            if constexpr (ks == ks0) *psig = cp[0];
+        } else if constexpr (kind != PK_NONE) {
+            Slab* po = (t == 0) ? pout : out;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (ks0 + p * span / 8 == ks) epi_piece<PREC, SV, pl>(cx, st, cp, po, pt, p);
+        }
+        // ---- bias of the next tile into the accumulator the epilogue just freed ----
+        constexpr int KB = (ks0 + span < NKS - 1) ? ks0 + span : NKS - 1;
+        if constexpr (ks == KB) {
+            if constexpr (t + 1 < NT) pipe_bias<L, t + 1>(cx, cp);
+            else if constexpr (NL >= 0) pipe_bias<(NL >= 0 ? NL : 0), 0>(cx, cp);
+            if constexpr (F8 && t == 0 && (PK == PK_RELU || PK == PK_LINEAR)) {
+                // the pending layer's output section is complete: its scale (one reduction), recorded in the tile's scale table
+                const unsigned mh = cx.mx >> 16, ml = cx.mx & 0xffffu;
+                cx.sb = f8_scale_byte(wave_max_u32((mh > ml ? mh : ml) << 16));
+                cx.mx = 0u;
+                save_scale_f8(st.pending, cx.tile, f8_act_scale_off(), f8_x_section(layer_out_sec(PL >= 0 ? PL : 0)), cx.sb, fresh_lane());
+            }
+        }
+        // ---- fp8 storage: this tile's share of the layer's INPUT pairs ----
+        if constexpr (F8 && PREC == NERFHIP_BF16 && layer_in_sec(L) >= 0) {
+            constexpr int NP = ly.chain_slabs / 2;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (q >= t * NP / NT && q < (t + 1) * NP / NT) {
+                    const int j = q - t * NP / NT;
+                    const int step = (KB + 1 + j < NKS - 1) ? KB + 1 + j : NKS - 1;
+                    if (step == ks) save_pair_f8(st.pending, cx.tile, layer_in_sec(L) / 2 + q, chain[2 * q], chain[2 * q + 1], cx.sb, fresh_lane());
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // ---- input encodings in slot order (mlp_layout.h: enc_slot_channel) -----------------------------
 // computed from the raw 3-vector: half h evaluates frequencies k = 2i+h; one sincos -> two slots
 template <int F, int SLABS, typename Slab>
@@ -460,7 +697,14 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     // LDS: weight ring | per-wave bias copy (1 KiB) | per-wave input-encoding stash (6 slabs: the encodings are
     // needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) / 48 (fp32) registers)
     constexpr int kEncStash = (kXyzSlabs + kDirSlabs) * 64 * (int)sizeof(Slab);
-    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * kPieceBytes + NW * kEncStash];
+    constexpr bool PIPE = NERFHIP_PIPE;
+    // PIPE: one workgroup-shared image of all 12 bias pieces instead of a per-wave copy of the current layer's
+    constexpr int kBiasArea = PIPE ? kNumLayers * kPieceBytes : NW * kPieceBytes;
+    // LDS: PIPE: [bias image | ring | stash] (small offsets for the bias reads); otherwise [ring | bias copies | stash]
+    __shared__ __attribute__((aligned(1024))) char lds_all[kSlots * kChunkBytes + kBiasArea + NW * kEncStash];
+    char* const ring = lds_all + (PIPE ? kBiasArea : 0);
+    char* const bias_area = PIPE ? lds_all : lds_all + kSlots * kChunkBytes;
+    char* const stash_area = lds_all + kSlots * kChunkBytes + kBiasArea;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -491,15 +735,27 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     st.lds_base = (unsigned)(uintptr_t)ring;
     st.wave = wave;
     st.pending = 0;
+    st.pending_prev = 0;
     // wave-uniform base of this wave's activation block (SAVE); the store helpers derive descriptors from it
     uint8_t* tile_base = SAVE ? save + ((size_t)blockIdx.x * NW + wave) * (F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC))
                               : (uint8_t*)nullptr;
 
+    if constexpr (PIPE) {
+        // bias image: the in-stream bias piece of every layer this kernel runs, DMA'd once (older than chunk 0's DMAs, so
+        // the first chunk boundary's vmcnt wait + barrier covers it)
+        constexpr int NLY = SIGMA_ONLY ? kSigmaLayer + 1 : kNumLayers;
+        static_for<0, NLY>([&](auto lc) {
+            constexpr int Lb = decltype(lc)::value;
+            if (wave == Lb % NW)
+                glds16(st.gsrc + (size_t)layer_start(Lb, PREC) * kPieceBytes,
+                       (unsigned)(uintptr_t)bias_area + (unsigned)(Lb * kPieceBytes));
+        });
+    }
     st.issue_chunk(0);
     if (NCH > 1) st.issue_chunk(1);
 
     const char* smem_lane = ring + lane * 16;
-    char* smem_half = ring + kSlots * kChunkBytes + wave * kPieceBytes;    // this wave's private bias copy (run_layer)
+    char* smem_half = bias_area + wave * kPieceBytes;    // this wave's private bias copy (run_layer)
 
     Slab encx[kXyzSlabs];
     Slab encd[kDirSlabs];
@@ -524,7 +780,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
         save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
     }
-    char* enc_x = ring + kSlots * kChunkBytes + NW * kPieceBytes + wave * kEncStash;      // wave-uniform stash bases
+    char* enc_x = stash_area + wave * kEncStash;      // wave-uniform stash bases
     char* enc_d = enc_x + kXyzSlabs * 64 * (int)sizeof(Slab);
 #pragma unroll
     for (int k = 0; k < kXyzSlabs; ++k) *reinterpret_cast<Slab*>(enc_x + lane * (int)sizeof(Slab) + k * 64 * (int)sizeof(Slab)) = encx[k];
@@ -535,6 +791,53 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
     Slab ha[16], hb[16];
     f32x16 raw;
+    if constexpr (PIPE) {
+        using Ctx = PipeCtx<PREC, SV, Slab>;
+        Ctx cx;
+        cx.smem_lane = smem_lane;
+        cx.bias_lane = bias_area + h * 16;
+        cx.enc_x = enc_x + lane * (int)sizeof(Slab);
+        cx.enc_d = enc_d + lane * (int)sizeof(Slab);
+        cx.tile = tile_base;
+        cx.gw[0] = cx.gw[1] = cx.gw[2] = cx.gw[3] = 0u;
+        cx.mx = 0u;
+        cx.sb = 127;
+        static_for<0, Ctx::D>([&](auto jc) { pipe_prefetch<PREC, NCH, 0, decltype(jc)::value>(cx, st); });
+        pipe_bias<0, 0>(cx, cx.acc[0]);
+        float sigma_p = 0.0f;
+        Slab* const nul = nullptr;
+        //                            L  NL  PAR0  pending layer
+        run_layer_pipe<PREC, NCH, SV, 0, 1, 0, -1>(cx, st, (const Slab*)nullptr, ha, nul, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 1, 2, 0, 0>(cx, st, ha, hb, ha, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 2, 3, 0, 1>(cx, st, hb, ha, hb, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 3, 4, 0, 2>(cx, st, ha, hb, ha, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 4, 5, 0, 3>(cx, st, hb, ha, hb, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 5, 6, 0, 4>(cx, st, ha, hb, ha, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 6, 7, 0, 5>(cx, st, hb, ha, hb, &sigma_p);
+        run_layer_pipe<PREC, NCH, SV, 7, 8, 0, 6>(cx, st, ha, hb, ha, &sigma_p);          // h8 -> hb
+        // sigma head (tile 64, accumulator 0); finishes h8's last tile first
+        run_layer_pipe<PREC, NCH, SV, 8, (SIGMA_ONLY ? -1 : 9), 0, 7>(cx, st, hb, nul, hb, &sigma_p);
+        if constexpr (SIGMA_ONLY) {
+            if (valid && h == 0) out[p] = cx.acc[0][0];          // (n,1)   nerf.py:112-114
+            return;
+        } else {
+            run_layer_pipe<PREC, NCH, SV, 9, 10, 1, 8>(cx, st, hb, ha, nul, &sigma_p);        // xyz_encoding_final (no activation) -> ha
+            run_layer_pipe<PREC, NCH, SV, 10, 11, 1, 9>(cx, st, ha, hb, ha, &sigma_p);        // dir_encoding -> hb[0..7]
+            run_layer_pipe<PREC, NCH, SV, 11, -1, 1, 10>(cx, st, hb, nul, hb, &sigma_p);      // rgb head, accumulator 1
+            // (SAVE: output index from a recomputed lane id, otherwise the prologue's 64-bit address stays live across the network)
+            const int lane_o = SAVE ? fresh_lane_opaque() : lane;
+            const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
+            if (po < n && (lane_o >> 5) == 0) {
+                float4 o;
+                o.x = 1.0f / (1.0f + expf(-cx.acc[1][0]));            // sigmoid   nerf.py:79-81
+                o.y = 1.0f / (1.0f + expf(-cx.acc[1][1]));
+                o.z = 1.0f / (1.0f + expf(-cx.acc[1][2]));
+                o.w = sigma_p;                                        // cat([rgb, sigma])   nerf.py:122
+                reinterpret_cast<float4*>(out)[po] = o;
+            }
+            return;
+        }
+    }
     int sb = 127;       // e8m0 scale byte of the section produced by the previous layer (F8)
 #define NH_LAYER(L, ENC, IN, OUT)                                                                               \
     sb = run_layer<PREC, L, NCH, 8, true, SV>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
