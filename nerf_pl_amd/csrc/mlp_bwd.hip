@@ -171,40 +171,6 @@ struct BwdStream {
     }
 };
 
-template <int PREC, int L, int NT, int NKS, typename Slab>
-__device__ __forceinline__ void run_bwd_layer(BwdStream<PREC>& st, const char* smem_lane, const Slab* gin,
-                                              f32x16 (&acc)[NT]) {
-    constexpr int G0 = bwd_layer_start(L, PREC);
-    constexpr int PPF = ppf(PREC);
-    static_assert(kBwdLayers[L].nt == NT && kBwdLayers[L].nks == NKS, "bwd layer shape mismatch");
-    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const Slab bs = gin[ks];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int g = G0 + (ks * NT + t) * PPF;
-            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
-            if constexpr (PREC == NERFHIP_BF16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bs, acc[t], 0, 0, 0);
-            } else {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
-                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bs[j], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
-
 template <typename Slab>
 __device__ __forceinline__ Slab load_slab(__amdgpu_buffer_rsrc_t rsrc, int sec, int lane) {
     Slab s;
@@ -245,45 +211,13 @@ __device__ __forceinline__ int dy_block_scale(float lane_max) {
 #endif
 }
 
-// acc (g wrt post-activation) -> slabs of g wrt pre-activation: multiply by relu'(pre-act), read as ONE 16-B
-// gate word per lane per layer (bit 8*ks+j, written by the forward's SAVE variant; mask_piece < 0 = no gate),
-// store as dY section, keep as next B operand.
-// F8: the section is stored as e4m3 slab pairs under ONE scale per (wave tile, layer) — a single DPP reduction at the layer
-// end (f8_store.h), recorded in the tile's scale table; `dy_tile` = base of the tile's dY block.
-template <int PREC, bool MASK, bool F8, int NT, typename Slab>
-__device__ __forceinline__ void finish_layer(BwdStream<PREC>& st, const f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t acts,
-                                             int gate_off, int mask_piece, __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile,
-                                             int dy_sec, Slab* out, int lane) {
-    u32x4 gates = {0u, 0u, 0u, 0u};
-    if (MASK)
-        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
-    float mx = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 2 * NT; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float gv = acc[ks >> 1][8 * (ks & 1) + j];
-            const int idx = 8 * ks + j;            // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd_kernel.h run_layer)
-            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)gates[idx >> 5], 31 - (idx & 31), 1);   // 0 | ~0
-            v[j] = MASK ? __uint_as_float(__float_as_uint(gv) & m) : gv;
-            if (F8) mx = fmaxf(mx, fabsf(v[j]));
-        }
-        mk_slab(out[ks], v);
-        if constexpr (!F8) store_slab(st, dys, dy_sec + ks, out[ks], lane);
-    }
-    if constexpr (F8 && PREC == NERFHIP_BF16) {
-#if NERFHIP_F8_DY_E5M2
-        const int sb = bf8_block_scale(mx);
-#pragma unroll
-        for (int q = 0; q < NT; ++q) save_pair_bf8(st.pending, dy_tile, dy_sec / 2 + q, out[2 * q], out[2 * q + 1], sb, lane);
-#else
-        const int sb = f8_block_scale(mx);
-#pragma unroll
-        for (int q = 0; q < NT; ++q) save_pair_f8(st.pending, dy_tile, dy_sec / 2 + q, out[2 * q], out[2 * q + 1], sb, lane);
-#endif
-        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
-    }
+// sign-extended one-bit field of a gate word: 0 or ~0.  (As inline asm: written with the builtin or plain C, hipcc turns the
+// constant-position extract + AND into v_and + v_cmp + v_cndmask, three VALU per value instead of two.)
+template <int BIT>
+__device__ __forceinline__ unsigned gate_mask(unsigned word) {
+    unsigned m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
+    return m;
 }
 
 template <int B, int E, typename F>
@@ -294,7 +228,7 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
     }
 }
 
-// ---- one backward layer, OUTPUT-TILE-MAJOR (NERFHIP_CHAIN_TILE_MAJOR): for each 32-row tile t of g_h(l-1) = W_l^T g_a(l):
+// ---- one backward layer, OUTPUT-TILE-MAJOR: for each 32-row tile t of g_h(l-1) = W_l^T g_a(l):
 // 16-17 chained MFMAs over the input slabs, then the tile's epilogue — ReLU gate, bf16 pack into slabs 2t, 2t+1 of the OTHER
 // slab set (a layer reads one set while its tiles fill the other), stores — which overlaps the next tile's MFMAs (other
 // accumulator) instead of forming one ~420-instruction VALU block per layer during which the matrix pipe idles.
@@ -347,19 +281,22 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char*
                         save_dy_pair(st.pending, dy_tile, in_sec / 2 + q, gin[2 * q], gin[2 * q + 1], in_sb, lane);
             }
         }
-        // ---- epilogue of tile t ----
+        // ---- epilogue of tile t: g wrt pre-activation = g * relu'(pre-act) (gate bit: mlp_layout.h gate_word / gate_bit) ----
+        float v[16];
+        bwd_static_for<0, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;           // slab 2t + (r >> 3), slot r & 7
+            constexpr int idx = 8 * (2 * t) + r;
+            const float gv = acc[r];
+            if constexpr (MASK) v[r] = __uint_as_float(__float_as_uint(gv) & gate_mask<gate_bit(idx)>(gates[gate_word(idx)]));
+            else v[r] = gv;
+            if (F8) mx = fmaxf(mx, fabsf(v[r]));
+        });
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            float v[8];
+            float v8[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float gv = acc[8 * sl + j];
-                const int idx = 8 * (2 * t + sl) + j;      // gate bit: word idx>>5, bit 31-(idx&31)  (mlp_fwd_kernel.h run_layer)
-                const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)gates[idx >> 5], 31 - (idx & 31), 1);   // 0 | ~0
-                v[j] = MASK ? __uint_as_float(__float_as_uint(gv) & m) : gv;
-                if (F8) mx = fmaxf(mx, fabsf(v[j]));
-            }
-            mk_slab(out[2 * t + sl], v);
+            for (int j = 0; j < 8; ++j) v8[j] = v[8 * sl + j];
+            mk_slab(out[2 * t + sl], v8);
             if constexpr (!F8) store_slab(st, dys, dy_sec + 2 * t + sl, out[2 * t + sl], lane);
         }
     });
@@ -448,7 +385,6 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
         store_slab(st, dys, kDySigma + 1, zero_slab, lane);
     }
 
-#if NERFHIP_CHAIN_TILE_MAJOR
     // scale bytes of the sections produced so far (F8); rgb / sigma pairs were stored above
     Slab gd[8];
     Slab ga[17], gb[17];
@@ -471,29 +407,6 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
 #pragma unroll
         for (int q = 0; q < 8; ++q) save_dy_pair(st.pending, dy_tile, dy_h(1) / 2 + q, ga[2 * q], ga[2 * q + 1], sb, lane);
     }
-#else
-    // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)
-    Slab gd[8];
-    {
-        f32x16 a4[4];
-        run_bwd_layer<PREC, 0, 4, 1>(st, smem_lane, &g_rgb, a4);
-        finish_layer<PREC, true, F8>(st, a4, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir, gd, lane);
-    }
-    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)
-    f32x16 acc[8];
-    Slab gs[17];
-    run_bwd_layer<PREC, 1, 8, 8>(st, smem_lane, gd, acc);
-    finish_layer<PREC, false, F8>(st, acc, acts, kGateOff, 0, dys, dy_tile, kDyFeat, gs, lane);
-    gs[16] = g_sig;
-    // final^T + sigma^T : g_h8 ; mask with h8
-    run_bwd_layer<PREC, 2, 8, 17>(st, smem_lane, gs, acc);
-    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8), gs, lane);
-#define NH_BWD(L)                                                                     \
-    run_bwd_layer<PREC, L, 8, 16>(st, smem_lane, gs, acc);                             \
-    finish_layer<PREC, true, F8>(st, acc, acts, kGateOff, mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), gs, lane);
-    NH_BWD(3) NH_BWD(4) NH_BWD(5) NH_BWD(6) NH_BWD(7) NH_BWD(8) NH_BWD(9)
-#undef NH_BWD
-#endif
 }
 
 // ================================================================================================

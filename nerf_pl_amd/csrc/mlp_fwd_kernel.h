@@ -9,6 +9,8 @@
 // the weights — pre-packed in A-fragment order — are DMA'd global->LDS (global_load_lds_dwordx4,
 // lane-linear 1 KiB pieces) into a 3-slot x 32 KiB ring shared by the workgroup's waves, with one
 // s_barrier per 32 KiB chunk and two chunks always in flight (counted vmcnt, never drained to 0).
+// Layers run output tile by output tile, software-pipelined: the epilogue of tile t is emitted between the
+// MFMAs of tile t+1 (see "Software-pipelined layer" below).
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, 8 waves (2 per SIMD) = 256 points / workgroup
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), 4 waves (1 per SIMD) = 128 points / workgroup
 #pragma once
@@ -18,9 +20,6 @@
 #include "mlp_layout.h"
 #include "f8_store.h"
 
-#ifndef NERFHIP_TILE_SCHED_BARRIER
-#define NERFHIP_TILE_SCHED_BARRIER 0
-#endif
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2     // cache-policy bits of the activation stores: 2 = nt (written once, read by another kernel: -7 %)
 #endif
@@ -51,20 +50,13 @@ template <> struct PrecTraits<NERFHIP_F32> {
     using Slab = f32x8;                  // 8 VGPRs
 };
 
-// Launch geometry.  bf16: 8 waves (2 per SIMD, 256 regs each) = 256 points / workgroup, the two waves of a SIMD
-// overlap each other's epilogue VALU / activation stores with MFMA.  fp32: 4 waves (1 per SIMD, 512 regs; an fp32
-// slab set is 128 registers).  NERFHIP_SAVE8=0 builds the bf16 training (SAVE) variant with 4 waves as well.
+// Launch geometry.  bf16: 8 waves (2 per SIMD, 256 regs each) = 256 points / workgroup: the second wave of a SIMD
+// fills the matrix pipe while the first waits (LDS, chunk barrier) or issues its epilogue VALU.  fp32: 4 waves (1 per
+// SIMD, 512 regs; an fp32 slab set is 128 registers).  (Round 1 measured a 4-wave/512-register bf16 activation-saving
+// build as bimodal across MI355X boxes — 376 us on some, ~900 us on others, same binary — hence 8 waves everywhere.)
 template <int PREC, bool SAVE> struct KCfg {
-#ifndef NERFHIP_SAVE8
-#define NERFHIP_SAVE8 1    // measured: the 4-wave/512-register SAVE build is bimodal across MI355X boxes (376 us on some,
-#endif                     // ~900 us on others, same binary); the 8-wave build is 460-520 us everywhere
-    static constexpr int NW = (PREC == NERFHIP_BF16 && (!SAVE || NERFHIP_SAVE8)) ? 8 : 4;
-    static constexpr int WPS = (PREC == NERFHIP_BF16 && (!SAVE || NERFHIP_SAVE8)) ? 2 : 1;
-    // A-fragment software prefetch depth (bf16): LDS reads issued this many MFMAs ahead of their use, so the
-    // ~100-cycle ds_read latency is not exposed once per 32-cycle MFMA
-    // (measured at 1024x192: inference forward 197 us with depth 2 vs 204 with depth 1; the 8-wave SAVE variant the
-    //  other way round, 238 vs 257 us — its registers are better spent elsewhere)
-    static constexpr int PF = (PREC != NERFHIP_BF16) ? 1 : (SAVE ? (NERFHIP_SAVE8 ? 1 : 8) : NERFHIP_PF2);
+    static constexpr int NW = (PREC == NERFHIP_BF16) ? 8 : 4;
+    static constexpr int WPS = (PREC == NERFHIP_BF16) ? 2 : 1;
 };
 
 __device__ __forceinline__ void make_slab(bf16x8& s, const float (&v)[8]) {
@@ -171,15 +163,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // followed by a VALU write of the data VGPR" hazard cannot occur and lets the next VALU instruction overwrite
 // v[d:d+3] right behind the store — on gfx950 that corrupts lanes 12-15 of every 16 (measured: dY slabs with
 // 0x4000 patterns from the following v_and).  With soffset = 0 the compiler inserts the wait states.
-template <int PREC, int NCH, bool CS>
-__device__ __forceinline__ void save_gates(WeightStream<PREC, NCH, CS>& st, uint8_t* tile_ptr, int gate_off, int piece,
-                                           const u32x4& g, int lane) {
-    // section offset goes into the descriptor BASE (SALU), soffset = 0 (gfx950 store-data hazard, see save_slabs)
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + gate_off + piece * kPieceBytes, 0,
-                                                                  kPieceBytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(g, rs, (unsigned)lane * 16u, 0, 0);
-    st.pending += 1;
-}
 template <int PREC, int NCH, typename Slab, bool CS>
 __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, uint8_t* tile_ptr, int sec,
                                            const Slab* slabs, int n, int lane) {
@@ -201,13 +184,6 @@ __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, uint
     }
 }
 
-__device__ __forceinline__ float slab_absmax(const bf16x8& s) {
-    float m = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)s[j]));
-    return m;
-}
-
 // The lane id, recomputed (v_mbcnt): a value the register allocator can drop and recreate instead of keeping the prologue's
 // copy — and everything derived from it — live (at the 256-register limit: spilled to scratch) across the whole network.
 __device__ __forceinline__ int fresh_lane() {
@@ -221,181 +197,20 @@ __device__ __forceinline__ int fresh_lane_opaque() {
     return l;
 }
 
-// ---- one layer, OUTPUT-TILE-MAJOR: for each 32-row output tile t: acc = bias; acc += W_frag(t,ks) * B[ks] over all
-// input slabs ks; then that tile's epilogue (activation, pack to the next layer's B slabs 2t and 2t+1, ReLU gate
-// bits, activation stores) runs while the matrix pipe already works on tile t+1 (other accumulator).  The
-// epilogue VALU is thereby spread over the layer in 1/NT portions instead of one block at the layer end, where —
-// all waves being chunk-synchronised by the weight ring's barriers — it used to stall every SIMD's MFMA pipe at once.
-// Weights are packed in the same (t, ks) order (mlp_pack.hip); fragment i = t*NKS + ks = piece G0 + 1 + i*PPF.
-//   out != nullptr : `out[2t], out[2t+1]` receive the activated slabs;   heads (NT == 1) return the raw tile in *raw.
-// fp8 storage (SV == 2): a layer stores its INPUT slabs (`chain` = the previous layer's activations, section `in_sec`, live in
-// registers for the whole layer) instead of its outputs — pair by pair in its tile epilogues, under the e8m0 scale byte
-// `in_sb` the previous layer computed with ONE wave reduction at its end — and returns the scale byte of its own output
-// (the per-lane max is folded into the epilogues: 8 v_max3 per tile).  The conversions therefore depend on nothing the
-// tile just computed: no reduction latency sits in any tile epilogue (a per-tile scale made this kernel 60 % slower).
-template <int PREC, int L, int NCH, int NT, bool RELU, int SV, typename Slab>
-__device__ __forceinline__ int run_layer(WeightStream<PREC, NCH, (SV != 0)>& st, const char* smem_lane, char* bias_priv,
-                                         const char* enc_lds, const Slab* chain, Slab* out, f32x16* raw,
-                                         uint8_t* rsrc, int act_sec, int gate_piece, int lane, int in_sec = -1, int in_sb = 127) {
-    constexpr bool SAVE = SV != 0, F8 = SV == 2;
-    static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
-    lane = SAVE ? fresh_lane() : lane;
-    constexpr Layer ly = kLayers[L];
-    static_assert(ly.nt == NT, "tile count mismatch");
-    constexpr int G0 = layer_start(L, PREC);
-    constexpr int PPF = ppf(PREC);
-    constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
-    constexpr int N = NT * NKS;
-    constexpr int D = (KCfg<PREC, SAVE>::PF < N) ? KCfg<PREC, SAVE>::PF : N;    // A-fragment prefetch depth
-
-    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
-    // A fragment i: bf16 = one 16-B read per lane; fp32 = two (8 x f32)
-    auto load_frag = [&](auto ic, Slab& a) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int g = G0 + 1 + i * PPF;
-        st.template at_piece<g>();
-        if constexpr (PREC == NERFHIP_BF16) {
-            a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
-        } else {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
-            st.template at_piece<g + 1>();
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { a[j] = a0[j]; a[4 + j] = a1[j]; }
-        }
-    };
-
-    st.template at_piece<G0>();
-    // The layer's bias piece is needed at the start of EVERY output tile, by which time its ring slot may have been
-    // refilled (a layer spans up to 5 chunks): copy it once into this wave's private 1 KiB of LDS (same-wave LDS
-    // operations execute in order, so no barrier is needed).
-    {
-        const u32x4 bv = *reinterpret_cast<const u32x4*>(smem_lane + piece_off(G0));
-        *reinterpret_cast<u32x4*>(bias_priv + lane * 16) = bv;
-    }
-    Slab a[D];
-    static_for<0, D>([&](auto ic) { load_frag(ic, a[decltype(ic)::value]); });
-
-#ifndef NERFHIP_GATE_DWORD_STORES
-#define NERFHIP_GATE_DWORD_STORES 1   // store each 32-bit gate word as soon as its two tiles are done (one live register
-#endif                                // instead of four: the activation-saving kernels run at the 256-register limit)
-    f32x16 acc[2];
-    unsigned gw[4] = {0u, 0u, 0u, 0u};
-    float mx = 0.0f;                                   // F8: this lane's max |output| of the layer
-
-    static_for<0, N>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int t = frag_tile(i, NT, NKS), ks = frag_slab(i, NT, NKS);
-        f32x16& c = acc[t & 1];
-        if constexpr (ks == 0) {
-            // bias -> accumulator init.  Row of reg r: 32t + (r&3) + 8(r>>2) + 4h  => one f32x4 per (t, r>>2)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bias_priv + (lane >> 5) * 16 + (32 * t + 8 * q) * 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) c[4 * q + k] = b[k];
-            }
-        }
-        // B operand: an input-encoding slab (parked in this wave's LDS stash)
-        // or a slab of the previous layer's activations (registers)
-        Slab bs;
-        if constexpr (ks < ly.enc_slabs)      // (enc_lds = the wave's stash base; the lane offset is added here, from the fresh lane id)
-            bs = *reinterpret_cast<const Slab*>(enc_lds + lane * (int)sizeof(Slab) + ks * 64 * (int)sizeof(Slab));
-        else bs = chain[ks - ly.enc_slabs];
-        if constexpr (PREC == NERFHIP_BF16) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % D], bs, c, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i % D][j], bs[j], c, 0, 0, 0);
-        }
-        if constexpr (i + D < N) load_frag(std::integral_constant<int, i + D>{}, a[i % D]);
-
-#ifndef NERFHIP_F8_CVT_AT_START
-#define NERFHIP_F8_CVT_AT_START 0
-#endif
-        if constexpr (ks == (NERFHIP_F8_CVT_AT_START ? 0 : NKS - 1)) {
-            if constexpr (F8 && PREC == NERFHIP_BF16) {
-                // this tile's share of the layer's INPUT pairs (chain_slabs / 2 pairs spread over the NT tiles, issued in
-                // bursts of NERFHIP_F8_BURST tiles' worth: consecutive pairs are contiguous KiBs of HBM)
-#ifndef NERFHIP_F8_BURST
-#define NERFHIP_F8_BURST 1
-#endif
-                constexpr int NP = ly.chain_slabs / 2, BU = (NERFHIP_F8_BURST < NT) ? NERFHIP_F8_BURST : NT;
-                constexpr int q0 = (t % BU == 0) ? t * NP / NT : 0, q1 = (t % BU == 0) ? (t + BU) * NP / NT : 0;
-                if (in_sec >= 0) {
-#pragma unroll
-                    for (int q = q0; q < q1; ++q)
-                        save_pair_f8(st.pending, rsrc, in_sec / 2 + q, chain[2 * q], chain[2 * q + 1], in_sb, lane);
-                }
-            }
-        }
-        if constexpr (ks == NKS - 1) {                       // ---- epilogue of tile t ----
-            if constexpr (NT == 1) {                         // heads: hand the raw tile back
-                *raw = c;
-            } else {
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = c[8 * sl + j];
-                        v[j] = RELU ? fmaxf(x, 0.0f) : x;
-#if NERFHIP_F8EXP != 3
-                        if (F8) mx = fmaxf(mx, RELU ? v[j] : fabsf(v[j]));
-#endif
-                        if (RELU && SAVE && NERFHIP_F8EXP != 4) {
-                            // ReLU gate of value idx = 8*(2t+sl) + j -> word idx>>5, bit 31-(idx&31).  Pure VALU (no
-                            // v_cmp: 128 live SGPR lane masks per layer spill): relu(x) is +-0 or positive, so bit 31 of
-                            // (bits + 0x7fffffff) is [x > 0]; v_alignbit pushes it into the word.
-                            const int idx = 8 * (2 * t + sl) + j;
-                            const unsigned sb = __float_as_uint(v[j]) + 0x7fffffffu;
-                            gw[idx >> 5] = __builtin_amdgcn_alignbit(gw[idx >> 5], sb, 31);   // (gw << 1) | (sb >> 31)
-                        }
-                    }
-                    make_slab(out[2 * t + sl], v);
-                }
-                if constexpr (SAVE && !F8) save_slabs(st, rsrc, act_sec + 2 * t, &out[2 * t], 2, lane);
-                if constexpr (SAVE && RELU && NERFHIP_GATE_DWORD_STORES && (t & 1) == 1) {
-                    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-                        rsrc + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) + gate_piece * kPieceBytes, 0, kPieceBytes, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b32(gw[t >> 1], grs, (unsigned)lane * 16u + 4u * (t >> 1), 0, 0);
-                    st.pending += 1;
-                }
-            }
-#if NERFHIP_TILE_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from stretching live ranges across tiles
-#endif
-        }
-    });
-    if constexpr (SAVE && RELU && NT != 1 && !NERFHIP_GATE_DWORD_STORES) {
-        u32x4 g;
-        g[0] = gw[0]; g[1] = gw[1]; g[2] = gw[2]; g[3] = gw[3];
-        save_gates(st, rsrc, F8 ? f8_act_gate_off() : act_mask_off(PREC), gate_piece, g, lane);
-    }
-    if constexpr (F8 && NT != 1) {
-        // scale of this layer's OUTPUT section (one reduction per layer), recorded in the tile's scale table
-        const int sb = f8_block_scale(mx);
-        save_scale_f8(st.pending, rsrc, f8_act_scale_off(), f8_x_section(act_sec), sb, lane);
-        return sb;
-    }
-    return 127;
-}
-
 // ====================================================================================================================
-// Software-pipelined layer (NERFHIP_PIPE): the epilogue of output tile t (activation, pack into the next layer's B slabs)
-// is EMITTED, in eight 2-value pieces, between the first MFMAs of tile t+1 — which accumulates into the other accumulator —
-// and the bias of tile t+2 is read into the freed accumulator a few MFMAs later; a layer's last tile is finished inside
-// the next layer's first tile (its slabs 2(NT-1), 2(NT-1)+1 are not consumed before slab step enc_slabs + 2(NT-1)).  A
-// `sched_barrier` after every MFMA step pins that order.  Before: hipcc kept the tile epilogue (s_nop + ~50 VALU + 4 bias
-// reads + wait) in one block BETWEEN tiles and merged the two accumulators into one register set, so every 16 MFMAs each
-// wave — and, the waves of a SIMD being chunk-synchronised by the ring barriers, the whole SIMD — left the matrix pipe
-// idle for ~400 cycles.
+// Software-pipelined layer.  A layer runs output tile by output tile: acc = bias; acc += W_frag(t, ks) * B[ks] over the
+// input slabs ks (weights packed in the same (t, ks) order, mlp_pack.hip).  The epilogue of tile t (activation, pack into the
+// next layer's B slabs 2t, 2t+1, gate bits, stores) is EMITTED, in eight 2-value pieces, between the first MFMAs of tile
+// t+1 — which accumulates into the other accumulator — and the bias of tile t+2 is read into the freed accumulator a few
+// MFMAs later; a layer's last tile is finished inside the next layer's first tile (its slabs 2(NT-1), 2(NT-1)+1 are not
+// consumed before slab step enc_slabs + 2(NT-1)).  A `sched_barrier` after every MFMA step pins that order.
+// (Left to itself hipcc keeps a tile's epilogue — s_nop + ~50 VALU + 4 bias reads + wait — in one block BETWEEN the tiles
+// and merges the two accumulators into one register set: every 16 MFMAs each wave, and — the waves of a SIMD being
+// chunk-synchronised by the ring barriers — the whole SIMD, left the matrix pipe idle for ~400 cycles.  Same-call A/B
+// at 1024x192 points: inference 182-188 -> 171-173 us, activation-saving e4m3 variant 281 -> 260-267 us.)
 // Biases are read from a workgroup-shared 12 KiB LDS image filled once in the prologue (the in-stream bias pieces still
 // travel through the ring; they are not read), A fragments and encoding operands are prefetched D steps ahead ACROSS
 // layer boundaries (fragment slots are numbered over the whole network).
-#ifndef NERFHIP_PIPE
-#define NERFHIP_PIPE 1
-#endif
 typedef __attribute__((ext_vector_type(2))) short nh_s16x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 nh_bf16x2;
 
@@ -460,12 +275,12 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
         o[2 * (p & 3)] = pk[0];
         o[2 * (p & 3) + 1] = pk[1];
         if (SAVE && RELU) {
-            // gate of value idx = 8*(2pt+sl) + j -> word idx>>5, bit 31-(idx&31) (values arrive in idx order): the halves are
-            // >= 0 after the ReLU, so bit 15 of (half + 0x7fff) is [half > 0]
-            const u16x2v k = {0x7fff, 0x7fff};
-            const unsigned tt = __builtin_bit_cast(unsigned, (u16x2v)(__builtin_bit_cast(u16x2v, pk) + k));
-            gw = (gw << 1) | ((tt >> 15) & 1u);
-            gw = __builtin_amdgcn_alignbit(gw, tt, 31);
+            // gate bits of this dword's two values (mlp_layout.h gate_bit: dword k of the word -> bit 15-k of each half-word):
+            // the halves are >= 0 after the ReLU, so min(half, 1) = [half > 0]; shift the word's half-words left and add
+            const u16x2v one = {1, 1};
+            const u16x2v tt = __builtin_elementwise_min(__builtin_bit_cast(u16x2v, pk), one);
+            const u16x2v g2 = __builtin_bit_cast(u16x2v, gw);
+            gw = __builtin_bit_cast(unsigned, (u16x2v)(g2 + g2 + tt));
         }
         if (F8) {       // running maximum of the STORED magnitudes: non-negative bf16 halves order like unsigned integers
             unsigned d = __builtin_bit_cast(unsigned, pk);
@@ -479,7 +294,11 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
             // max(bits, 0) as signed integers == relu for every non-NaN float (negative floats are negative integers)
             const float r = RELU ? __int_as_float(max(__float_as_int(x), 0)) : x;
             o[2 * (p & 3) + k] = r;
-            if (SAVE && RELU) gw = __builtin_amdgcn_alignbit(gw, __float_as_uint(r) + 0x7fffffffu, 31);
+            if (SAVE && RELU) {     // bit 31 of (bits + 0x7fffffff) is [r > 0] for r >= +0
+                const int idx = 8 * (2 * pt + (p >> 2)) + 2 * (p & 3) + k;
+                if ((idx & 31) == 0) gw = 0u;
+                gw |= ((__float_as_uint(r) + 0x7fffffffu) >> 31) << gate_bit(idx);
+            }
         }
     }
     if constexpr (SAVE) {
@@ -545,8 +364,7 @@ __device__ __forceinline__ void run_layer_pipe(Ctx& cx, St& st, const Slab* chai
     constexpr int NN = layer_frags(NL);
     constexpr int PK = pend_kind(PL), PT = kLayers[PL >= 0 ? PL : 0].nt - 1;
     constexpr bool F8 = SV == 2;
-    static_assert(!NERFHIP_TILE_PAIRS, "the pipelined layer assumes tile-major fragment order");
-
+    
     static_for<0, N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = i / NKS, ks = i % NKS;
@@ -694,17 +512,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     constexpr bool SAVE = SV != 0, F8 = SV == 2;
     constexpr int NW = KCfg<PREC, SAVE>::NW;
     constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
-    // LDS: weight ring | per-wave bias copy (1 KiB) | per-wave input-encoding stash (6 slabs: the encodings are
-    // needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) / 48 (fp32) registers)
+    // LDS: bias image (one 1 KiB piece per layer, shared by the workgroup) | weight ring | per-wave input-encoding stash
+    // (6 slabs: the encodings are needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) /
+    // 48 (fp32) registers)
     constexpr int kEncStash = (kXyzSlabs + kDirSlabs) * 64 * (int)sizeof(Slab);
-    constexpr bool PIPE = NERFHIP_PIPE;
-    // PIPE: one workgroup-shared image of all 12 bias pieces instead of a per-wave copy of the current layer's
-    constexpr int kBiasArea = PIPE ? kNumLayers * kPieceBytes : NW * kPieceBytes;
-    // LDS: PIPE: [bias image | ring | stash] (small offsets for the bias reads); otherwise [ring | bias copies | stash]
-    __shared__ __attribute__((aligned(1024))) char lds_all[kSlots * kChunkBytes + kBiasArea + NW * kEncStash];
-    char* const ring = lds_all + (PIPE ? kBiasArea : 0);
-    char* const bias_area = PIPE ? lds_all : lds_all + kSlots * kChunkBytes;
-    char* const stash_area = lds_all + kSlots * kChunkBytes + kBiasArea;
+    constexpr int kBiasArea = kNumLayers * kPieceBytes;
+    __shared__ __attribute__((aligned(1024))) char lds_all[kBiasArea + kSlots * kChunkBytes + NW * kEncStash];
+    char* const bias_area = lds_all;
+    char* const ring = lds_all + kBiasArea;
+    char* const stash_area = ring + kSlots * kChunkBytes;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -740,7 +556,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     uint8_t* tile_base = SAVE ? save + ((size_t)blockIdx.x * NW + wave) * (F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC))
                               : (uint8_t*)nullptr;
 
-    if constexpr (PIPE) {
+    {
         // bias image: the in-stream bias piece of every layer this kernel runs, DMA'd once (older than chunk 0's DMAs, so
         // the first chunk boundary's vmcnt wait + barrier covers it)
         constexpr int NLY = SIGMA_ONLY ? kSigmaLayer + 1 : kNumLayers;
@@ -755,7 +571,6 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     if (NCH > 1) st.issue_chunk(1);
 
     const char* smem_lane = ring + lane * 16;
-    char* smem_half = bias_area + wave * kPieceBytes;    // this wave's private bias copy (run_layer)
 
     Slab encx[kXyzSlabs];
     Slab encd[kDirSlabs];
@@ -790,8 +605,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     }
     // activations ping-pong between two register slab sets (a layer reads one while its tiles fill the other)
     Slab ha[16], hb[16];
-    f32x16 raw;
-    if constexpr (PIPE) {
+    {
         using Ctx = PipeCtx<PREC, SV, Slab>;
         Ctx cx;
         cx.smem_lane = smem_lane;
@@ -836,51 +650,6 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
                 reinterpret_cast<float4*>(out)[po] = o;
             }
             return;
-        }
-    }
-    int sb = 127;       // e8m0 scale byte of the section produced by the previous layer (F8)
-#define NH_LAYER(L, ENC, IN, OUT)                                                                               \
-    sb = run_layer<PREC, L, NCH, 8, true, SV>(st, smem_lane, smem_half, ENC, IN, OUT, (f32x16*)nullptr, tile_base, \
-                                              act_h(L + 1), mask_piece_h(L + 1), lane, (L) == 0 ? -1 : act_h(L), sb);
-    NH_LAYER(0, enc_x, (const Slab*)nullptr, ha)
-    NH_LAYER(1, (const char*)nullptr, ha, hb)
-    NH_LAYER(2, (const char*)nullptr, hb, ha)
-    NH_LAYER(3, (const char*)nullptr, ha, hb)
-    NH_LAYER(4, enc_x, hb, ha)
-    NH_LAYER(5, (const char*)nullptr, ha, hb)
-    NH_LAYER(6, (const char*)nullptr, hb, ha)
-    NH_LAYER(7, (const char*)nullptr, ha, hb)              // h8 -> hb
-#undef NH_LAYER
-
-    run_layer<PREC, 8, NCH, 1, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
-                                          tile_base, 0, 0, lane);
-    const float sigma = raw[0];                              // row 0 lives in reg 0 of the h=0 lanes
-
-    if (SIGMA_ONLY) {
-        // (output index from a recomputed lane id: otherwise the 64-bit address computed in the prologue is kept live —
-        //  i.e. spilled to scratch — across the whole network)
-        const int lane_o = fresh_lane_opaque();
-        const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
-        if (po < n && (lane_o >> 5) == 0) out[po] = sigma;  // (n,1)   nerf.py:112-114
-        return;
-    } else {
-        // xyz_encoding_final: no activation (nerf.py:116) -> ha   (F8: stores its input h8)
-        sb = run_layer<PREC, 9, NCH, 8, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, ha, (f32x16*)nullptr,
-                                                   tile_base, kActFeat, 0, lane, act_h(8), sb);
-        // dir_encoding: relu(W [feat | dir])  (nerf.py:118-119) -> hb[0..7]   (F8: stores its input feat)
-        sb = run_layer<PREC, 10, NCH, 4, true, SV>(st, smem_lane, smem_half, enc_d, ha, hb, (f32x16*)nullptr, tile_base, kActT,
-                                                   kMaskPieceT, lane, kActFeat, sb);
-        run_layer<PREC, 11, NCH, 1, false, SV>(st, smem_lane, smem_half, (const char*)nullptr, hb, (Slab*)nullptr, &raw,
-                                               tile_base, 0, 0, lane, kActT, sb);                       // (F8: stores its input t)
-        const int lane_o = fresh_lane_opaque();
-        const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
-        if (po < n && (lane_o >> 5) == 0) {
-            float4 o;
-            o.x = 1.0f / (1.0f + expf(-raw[0]));            // sigmoid   nerf.py:79-81
-            o.y = 1.0f / (1.0f + expf(-raw[1]));
-            o.z = 1.0f / (1.0f + expf(-raw[2]));
-            o.w = sigma;                                     // cat([rgb, sigma])   nerf.py:122
-            reinterpret_cast<float4*>(out)[po] = o;
         }
     }
 }

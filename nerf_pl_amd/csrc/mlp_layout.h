@@ -85,21 +85,10 @@ NH_HD constexpr int chunks_upto_layer(int Lend, int prec) {   // chunks needed t
     return (layer_start(Lend, prec) + kChunkPieces - 1) / kChunkPieces;
 }
 
-// ---- fragment order inside a layer ------------------------------------------------------------------------
-// Default: output-tile-major, fragment i = (tile i / nks, slab i % nks).  NERFHIP_TILE_PAIRS=1 instead alternates
-// the MFMAs between the two accumulators of a tile pair — (tile 2P + (r & 1), slab r >> 1), P = i / (2 nks),
-// r = i % (2 nks) — so that no MFMA depends on the one issued right before it.  Measured (1024x192, same box):
-// inference forward 188 vs 194 us, but the activation-saving forward 390 vs 347 us (both tiles' epilogues and stores
-// land together: 30 spilled VGPRs), so it stays off.  Pack kernel and MLP kernels share these two functions.
-#ifndef NERFHIP_TILE_PAIRS
-#define NERFHIP_TILE_PAIRS 0
-#endif
-NH_HD constexpr int frag_tile(int i, int nt, int nks) {
-    return (NERFHIP_TILE_PAIRS && nt % 2 == 0) ? 2 * (i / (2 * nks)) + ((i % (2 * nks)) & 1) : i / nks;
-}
-NH_HD constexpr int frag_slab(int i, int nt, int nks) {
-    return (NERFHIP_TILE_PAIRS && nt % 2 == 0) ? (i % (2 * nks)) >> 1 : i % nks;
-}
+// ---- fragment order inside a layer: output-tile-major, fragment i = (tile i / nks, slab i % nks) -----------------------
+// (pack kernel and MLP kernels share these two functions)
+NH_HD constexpr int frag_tile(int i, int nt, int nks) { return i / nks; }
+NH_HD constexpr int frag_slab(int i, int nt, int nks) { return i % nks; }
 
 // ---- input-slot maps --------------------------------------------------------------------------
 // Encoding channel (reference order, nerf.py:33-38: [x, sin f0 x, cos f0 x, sin f1 x, ...]) held by
@@ -148,9 +137,14 @@ NH_HD constexpr int act_h(int l) { return kActH0 + 16 * (l - 1); }   // l = 1..8
 constexpr int kActFeat = kActH0 + 128;      // 16 slabs  xyz_encoding_final output (no activation)
 constexpr int kActT = kActFeat + 16;        // 8 slabs   dir_encoding output (post-ReLU)
 constexpr int kActSlabs = kActT + 8;        // 158
-// ReLU gates: after the slabs of a tile, one 1 KiB piece per gated layer (h1..h8, t): lane's 16 B hold, for value
-// idx = 8*ks + j (slab ks, slot j), [pre-activation > 0] at word idx>>5, bit 31-(idx&31).  The backward chain reads these 9 KiB per tile instead of
-// the 136 KiB of activation slabs.
+// ReLU gates: after the slabs of a tile, one 1 KiB piece per gated layer (h1..h8, t): a lane's 16 B are four words, word w
+// covering output tiles 2w, 2w+1 = the 32 values idx = 8*ks + j (slab ks = 4w .. 4w+3, slot j) the lane holds of them, i.e. the
+// 16 packed dwords k = (idx & 31) >> 1 the forward produces in order; [pre-activation > 0] of value idx is bit gate_bit(idx) of
+// word gate_word(idx): the even slots fill the low half-word, the odd slots the high one, first dword at the top (the forward
+// shifts the pair of gate bits of each packed bf16 dword in with two packed 16-bit operations).  The backward chain reads these
+// 9 KiB per tile instead of the 136 KiB of activation slabs.
+NH_HD constexpr int gate_word(int idx) { return idx >> 5; }
+NH_HD constexpr int gate_bit(int idx) { return 16 * (idx & 1) + 15 - ((idx & 31) >> 1); }
 constexpr int kMaskPieces = 9;
 NH_HD constexpr int mask_piece_h(int l) { return l - 1; }            // l = 1..8
 constexpr int kMaskPieceT = 8;
@@ -188,14 +182,10 @@ constexpr BwdLayer kBwdLayers[kNumBwdLayers] = {
     {2, 8, 16, 0, 0},    // L3^T
     {1, 8, 16, 0, 0},    // L2^T : g_a2 -> g_h1
 };
-// Fragment order inside a backward-chain layer.  Output-tile-major (as the forward): fragment f = (tile f / nks, slab f % nks),
-// so that a tile's epilogue (gate, pack, store) overlaps the next tile's MFMAs; NERFHIP_CHAIN_TILE_MAJOR=0 restores the
-// slab-major order of round 1 (all tiles accumulated side by side, one epilogue block per layer).
-#ifndef NERFHIP_CHAIN_TILE_MAJOR
-#define NERFHIP_CHAIN_TILE_MAJOR 1
-#endif
-NH_HD constexpr int bwd_frag_tile(int f, int nt, int nks) { return NERFHIP_CHAIN_TILE_MAJOR ? f / nks : f % nt; }
-NH_HD constexpr int bwd_frag_slab(int f, int nt, int nks) { return NERFHIP_CHAIN_TILE_MAJOR ? f % nks : f / nt; }
+// Fragment order inside a backward-chain layer: output-tile-major (as the forward), fragment f = (tile f / nks, slab f % nks),
+// so that a tile's epilogue (gate, pack, store) overlaps the next tile's MFMAs.
+NH_HD constexpr int bwd_frag_tile(int f, int nt, int nks) { return f / nks; }
+NH_HD constexpr int bwd_frag_slab(int f, int nt, int nks) { return f % nks; }
 NH_HD constexpr int bwd_layer_pieces(int L, int prec) { return kBwdLayers[L].nks * kBwdLayers[L].nt * ppf(prec); }
 NH_HD constexpr int bwd_layer_start(int L, int prec) {
     int g = 0;

@@ -31,7 +31,7 @@ def gate_bits(piece, nslab):
     for ks in range(nslab):
         for j in range(8):
             idx = 8 * ks + j
-            bits[:, ks, :, j] = ((w[:, :, idx >> 5] >> (31 - (idx & 31))) & 1).bool()
+            bits[:, ks, :, j] = ((w[:, :, idx >> 5] >> (16 * (idx & 1) + 15 - ((idx & 31) >> 1))) & 1).bool()   # mlp_layout.h gate_bit
     return bits
 for l in range(1, 9):
     h = slabs[:, 6 + 16 * (l - 1): 6 + 16 * l]          # (tiles,16,64,8)
