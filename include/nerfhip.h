@@ -151,6 +151,10 @@ int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, co
 size_t nerfhip_mlp_packed_bwd_bytes(int dtype);
 int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
                                  nerfhip_stream_t stream);
+/* both images (nerfhip_mlp_pack_weights + nerfhip_mlp_pack_weights_bwd) in ONE launch: what a training step needs
+ * of a model whose weights do not change between its forward and its backward                                   */
+int nerfhip_mlp_pack_weights_train(const float* const* weights_host, const float* const* biases_host, void* packed,
+                                   void* packed_bwd, int dtype, nerfhip_stream_t stream);
 size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype);
 int nerfhip_mlp_dw_splits(int64_t n_points, int dtype);   /* total (job, point-split) workgroups = partial slabs */
 size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nerfhip_mlp_fwd_rays": [_c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _int, _int, _c_void_p, _c_void_p],
     "nerfhip_mlp_packed_bwd_bytes": [_int],
     "nerfhip_mlp_pack_weights_bwd": [ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
+    "nerfhip_mlp_pack_weights_train": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p, _int, _c_void_p],
     "nerfhip_mlp_dy_bytes": [_i64, _int],
     "nerfhip_mlp_dw_splits": [_i64, _int],
     "nerfhip_mlp_dw_workspace_bytes": [_i64, _int],

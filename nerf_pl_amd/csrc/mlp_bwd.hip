@@ -87,51 +87,6 @@ __device__ __forceinline__ void glds16b_nt(const void* gsrc, unsigned lds_dst) {
 }
 
 // ================================================================================================
-// W^T packing for the chain
-// ================================================================================================
-struct WTable {
-    const float* w[12];
-};
-
-template <int PREC>
-__global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(WTable P, uint8_t* __restrict__ packed) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    const int m = lane & 31, h = lane >> 5;
-    uint4 outv = make_uint4(0, 0, 0, 0);
-    if (g < bwd_total_pieces(PREC)) {
-        int L = 0, start = 0;
-        while (L + 1 < kNumBwdLayers && g >= start + bwd_layer_pieces(L, PREC)) { start += bwd_layer_pieces(L, PREC); ++L; }
-        const BwdLayer ly = kBwdLayers[L];
-        const int rel = g - start;
-        const int f = rel / ppf(PREC), sub = rel % ppf(PREC);
-        const int ks = bwd_frag_slab(f, ly.nt, ly.nks), t = bwd_frag_tile(f, ly.nt, ly.nks);
-        const int icol = ly.col0 + 32 * t + m;                     // input feature of W == output row of W^T
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = 0.0f;
-            if (ly.sigma_slab && ks == ly.nks - 1) {                // sigma head: one real row (W_sigma[0][:])
-                if (h == 0 && j == 0) v[j] = P.w[10][icol];
-            } else {
-                const int o = chain_feature(ks, h, j);
-                if (o < kParamOut[ly.param] && icol < kParamIn[ly.param])
-                    v[j] = P.w[ly.param][(size_t)o * kParamIn[ly.param] + icol];
-            }
-        }
-        if (PREC == NERFHIP_BF16) {
-            bf16x8 p;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = (__bf16)v[j];
-            outv = *reinterpret_cast<uint4*>(&p);
-        } else {
-            outv = make_uint4(__float_as_uint(v[4 * sub + 0]), __float_as_uint(v[4 * sub + 1]),
-                              __float_as_uint(v[4 * sub + 2]), __float_as_uint(v[4 * sub + 3]));
-        }
-    }
-    reinterpret_cast<uint4*>(packed + (size_t)g * kPieceBytes)[lane] = outv;
-}
-
-// ================================================================================================
 // Phase A: backward chain
 // ================================================================================================
 template <int PREC>
@@ -855,31 +810,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
 // ================================================================================================
 static inline bool valid_dtype(int dtype) { return dtype == NERFHIP_F32 || dtype == NERFHIP_BF16 || dtype == NERFHIP_BF16_F8; }
 static inline int compute_prec(int dtype) { return dtype == NERFHIP_F32 ? NERFHIP_F32 : NERFHIP_BF16; }
-
-extern "C" size_t nerfhip_mlp_packed_bwd_bytes(int dtype) {
-    if (!valid_dtype(dtype)) return 0;
-    dtype = compute_prec(dtype);
-    return (size_t)nerfhip::mlp::bwd_padded_pieces(dtype) * nerfhip::mlp::kPieceBytes;
-}
-
-extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
-                                            nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(weights_host && packed_bwd);
-    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
-    dtype = compute_prec(dtype);
-    if (((uintptr_t)packed_bwd) & 15) return NERFHIP_E_ALIGN;
-    nerfhip::WTable P;
-    for (int i = 0; i < 12; ++i) {
-        NERFHIP_CHECK_ARG(weights_host[i]);
-        P.w[i] = weights_host[i];
-    }
-    const int n = nerfhip::mlp::bwd_padded_pieces(dtype);
-    if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
-    else
-        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
-    return nerfhip_launch_status();
-}
 
 static int64_t act_tiles(int64_t n_points, int dtype) {
     const int64_t ppw = 32 * (dtype == NERFHIP_F32 ? 4 : 8);

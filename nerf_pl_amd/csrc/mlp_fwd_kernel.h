@@ -234,6 +234,12 @@ NH_HD constexpr int layer_in_sec(int L) {
     return (L >= 1 && L <= 7) ? act_h(L) : (L == 9 ? act_h(8) : (L == 10 ? kActFeat : (L == 11 ? kActT : -1)));
 }
 
+#ifndef NERFHIP_EXP_NOPS
+#define NERFHIP_EXP_NOPS 0
+#endif
+#ifndef NERFHIP_EXP_SMALL
+#define NERFHIP_EXP_SMALL 0     // code-size experiment only (results invalid): no gate words, no running maximum
+#endif
 #ifndef NERFHIP_PF_SAVE
 #define NERFHIP_PF_SAVE 2
 #endif
@@ -248,11 +254,24 @@ struct PipeCtx {
     const char* enc_x;         // this lane's slot of the wave's encoding stash
     const char* enc_d;
     // activation-saving variants
-    uint8_t* tile;             // this wave's saved-activation block
+    uint8_t* tile;             // this wave's saved-activation block: slab / pair sections are addressed from here,
+    uint8_t* gate_base;        // its gate pieces from here and
+    uint8_t* scale_base;       // its scale dwords from here (three bases: the looped layer triples shift each by its own amount)
     unsigned gw[4];            // ReLU gate words of the layer in flight
     unsigned mx;               // fp8 storage: this lane's max |output| of the layer in flight, as two bf16 halves (even / odd values)
     int sb;                    // fp8 storage: e8m0 scale byte of the most recently finished section
 };
+
+// Gate bits of one packed dword of two post-ReLU bf16 values (mlp_layout.h gate_bit: dword k of a gate word -> bit 15-k of each
+// half-word): the halves are >= 0, so min(half, 1) = [half > 0]; both half-words of the gate word are shifted left by one and
+// the new bits added — two packed 16-bit VALU operations.  (Inline asm: written in C, hipcc canonicalises min(x, 1) to a
+// compare + select per half plus a v_perm, seven instructions and 50 bytes of code per dword.)
+__device__ __forceinline__ unsigned gate_shift_in(unsigned gw, unsigned d) {
+    unsigned t, r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(d));
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(gw), "v"(t));
+    return r;
+}
 
 // one 2-value piece p (0..7) of the epilogue of the finished tile `c` (tile pt of layer PL):
 // -> dword (p & 3) of slab 2*pt + (p >> 2) of `po`; SAVE: gate bits, slab / gate-word stores, running maximum
@@ -274,15 +293,8 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
         }
         o[2 * (p & 3)] = pk[0];
         o[2 * (p & 3) + 1] = pk[1];
-        if (SAVE && RELU) {
-            // gate bits of this dword's two values (mlp_layout.h gate_bit: dword k of the word -> bit 15-k of each half-word):
-            // the halves are >= 0 after the ReLU, so min(half, 1) = [half > 0]; shift the word's half-words left and add
-            const u16x2v one = {1, 1};
-            const u16x2v tt = __builtin_elementwise_min(__builtin_bit_cast(u16x2v, pk), one);
-            const u16x2v g2 = __builtin_bit_cast(u16x2v, gw);
-            gw = __builtin_bit_cast(unsigned, (u16x2v)(g2 + g2 + tt));
-        }
-        if (F8) {       // running maximum of the STORED magnitudes: non-negative bf16 halves order like unsigned integers
+        if (SAVE && RELU && !NERFHIP_EXP_SMALL) gw = gate_shift_in(gw, __builtin_bit_cast(unsigned, pk));
+        if (F8 && !NERFHIP_EXP_SMALL) {       // running maximum of the STORED magnitudes: non-negative bf16 halves order like unsigned integers
             unsigned d = __builtin_bit_cast(unsigned, pk);
             if (!RELU) d &= 0x7fff7fffu;
             cx.mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, cx.mx), __builtin_bit_cast(u16x2v, d)));
@@ -305,8 +317,8 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
         const int lane = fresh_lane();
         if (!F8 && (p & 3) == 3) save_slabs(st, cx.tile, layer_out_sec(PL) + 2 * pt + (p >> 2), &o, 1, lane);
         if (RELU && p == 7 && (pt & 1)) {
-            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-                cx.tile + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) + layer_gate_piece(PL) * kPieceBytes, 0, kPieceBytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(cx.gate_base + layer_gate_piece(PL) * kPieceBytes, 0,
+                                                                           kPieceBytes, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(gw, grs, (unsigned)lane * 16u + 4u * (unsigned)(pt >> 1), 0, 0);
             st.pending += 1;
         }
@@ -321,9 +333,14 @@ __device__ __forceinline__ void pipe_prefetch(Ctx& cx, St& st) {
     constexpr int NKS = ly.enc_slabs + ly.chain_slabs;
     constexpr int G0 = layer_start(L, PREC), PPF = ppf(PREC);
     constexpr int slot = (frag_base(L) + J) % Ctx::D;
-    constexpr int g = G0 + 1 + J * PPF;
+    constexpr int g = G0 + J * PPF;
     auto piece_off = [](int gg) { return ((gg / kChunkPieces) % kSlots) * kChunkBytes + (gg % kChunkPieces) * kPieceBytes; };
-    if constexpr (J == 0) st.template at_piece<G0>();        // the layer's in-stream bias piece (not read)
+    if constexpr (L == kLoopSecond && J == 0) {
+        // the bias block's chunks travel through the ring unread: run their boundaries (refills) all the same
+        static_for<0, bias_block_pieces(PREC) / kChunkPieces>([&](auto kc) {
+            st.template at_piece<bias_block_start(PREC) + decltype(kc)::value * kChunkPieces>();
+        });
+    }
     st.template at_piece<g>();
     if constexpr (PREC == NERFHIP_BF16) {
         cx.a[slot] = *reinterpret_cast<const bf16x8*>(cx.smem_lane + piece_off(g));
@@ -413,7 +430,7 @@ __device__ __forceinline__ void run_layer_pipe(Ctx& cx, St& st, const Slab* chai
                 const unsigned mh = cx.mx >> 16, ml = cx.mx & 0xffffu;
                 cx.sb = f8_scale_byte(wave_max_u32((mh > ml ? mh : ml) << 16));
                 cx.mx = 0u;
-                save_scale_f8(st.pending, cx.tile, f8_act_scale_off(), f8_x_section(layer_out_sec(PL >= 0 ? PL : 0)), cx.sb, fresh_lane());
+                save_scale_f8(st.pending, cx.scale_base, 0, f8_x_section(layer_out_sec(PL >= 0 ? PL : 0)), cx.sb, fresh_lane());
             }
         }
         // ---- fp8 storage: this tile's share of the layer's INPUT pairs ----
@@ -428,6 +445,9 @@ __device__ __forceinline__ void run_layer_pipe(Ctx& cx, St& st, const Slab* chai
                 }
             }
         }
+#if NERFHIP_EXP_NOPS      // code-size experiment only: pad every MFMA step with s_nop (tools: slow-box instruction-cache probe)
+        static_for<0, NERFHIP_EXP_NOPS>([&](auto) { asm volatile("s_nop 0"); });
+#endif
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -522,6 +542,12 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     char* const ring = lds_all + kBiasArea;
     char* const stash_area = ring + kSlots * kChunkBytes;
 
+#ifndef NERFHIP_CLOCK_PROBE
+#define NERFHIP_CLOCK_PROBE 0      // debug builds: every wave of the e4m3 activation-saving variant records its shader-clock cycles and
+#endif                             // 100 MHz wall ticks in spare dwords of its tile's scale piece (tools/kbench.py --clock-probe)
+#if NERFHIP_CLOCK_PROBE
+    const uint64_t probe_c0 = clock64(), probe_w0 = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
@@ -557,13 +583,13 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
                               : (uint8_t*)nullptr;
 
     {
-        // bias image: the in-stream bias piece of every layer this kernel runs, DMA'd once (older than chunk 0's DMAs, so
-        // the first chunk boundary's vmcnt wait + barrier covers it)
+        // bias image: the bias piece of every layer this kernel runs, DMA'd once from the stream's bias block (older than
+        // chunk 0's DMAs, so the first chunk boundary's vmcnt wait + barrier covers it)
         constexpr int NLY = SIGMA_ONLY ? kSigmaLayer + 1 : kNumLayers;
         static_for<0, NLY>([&](auto lc) {
             constexpr int Lb = decltype(lc)::value;
             if (wave == Lb % NW)
-                glds16(st.gsrc + (size_t)layer_start(Lb, PREC) * kPieceBytes,
+                glds16(st.gsrc + (size_t)(bias_block_start(PREC) + Lb) * kPieceBytes,
                        (unsigned)(uintptr_t)bias_area + (unsigned)(Lb * kPieceBytes));
         });
     }
@@ -609,10 +635,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         using Ctx = PipeCtx<PREC, SV, Slab>;
         Ctx cx;
         cx.smem_lane = smem_lane;
-        cx.bias_lane = bias_area + h * 16;
         cx.enc_x = enc_x + lane * (int)sizeof(Slab);
         cx.enc_d = enc_d + lane * (int)sizeof(Slab);
+        uint8_t* const gate0 = SAVE ? tile_base + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) : (uint8_t*)nullptr;
+        uint8_t* const scale0 = F8 ? tile_base + f8_act_scale_off() : (uint8_t*)nullptr;
+        const char* const bias0 = bias_area + h * 16;
         cx.tile = tile_base;
+        cx.gate_base = gate0;
+        cx.scale_base = scale0;
+        cx.bias_lane = bias0;
         cx.gw[0] = cx.gw[1] = cx.gw[2] = cx.gw[3] = 0u;
         cx.mx = 0u;
         cx.sb = 127;
@@ -622,13 +653,47 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         Slab* const nul = nullptr;
         //                            L  NL  PAR0  pending layer
         run_layer_pipe<PREC, NCH, SV, 0, 1, 0, -1>(cx, st, (const Slab*)nullptr, ha, nul, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 1, 2, 0, 0>(cx, st, ha, hb, ha, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 2, 3, 0, 1>(cx, st, hb, ha, hb, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 3, 4, 0, 2>(cx, st, ha, hb, ha, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 4, 5, 0, 3>(cx, st, hb, ha, hb, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 5, 6, 0, 4>(cx, st, ha, hb, ha, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 6, 7, 0, 5>(cx, st, hb, ha, hb, &sigma_p);
-        run_layer_pipe<PREC, NCH, SV, 7, 8, 0, 6>(cx, st, ha, hb, ha, &sigma_p);          // h8 -> hb
+        // ---- layers 1-3 and 5-7: ONE copy of the code, run twice (mlp_layout.h: same chunk phase, same ring slots; the second
+        // pass differs by wave-uniform base offsets only).  Fully unrolled, the network is 56 KiB (inference) to 90 KiB
+        // (activation-saving) of code against a 64 KiB instruction cache; some MI355X boxes run the 90 KiB kernel 1.5x slower
+        // than others for the instruction fetches alone (profiles/README.md "Box-to-box spread").
+        static_assert(kLoopFirst == 1 && kLoopSecond == 5 && kLoopLayers == 3, "loop below");
+        static_assert(layer_start(kLoopFirst, PREC) % kChunkPieces == 0 && loop_chunk_shift(PREC) % kSlots == 0 &&
+                          (layer_start(kLoopSecond, PREC) - layer_start(kLoopFirst, PREC)) % kChunkPieces == 0,
+                      "the two layer triples must see the same chunk phase and ring slots");
+        static_assert((frag_base(kLoopSecond) - frag_base(kLoopFirst)) % Ctx::D == 0, "... and the same fragment-ring slots");
+        const uint8_t* const gsrc0 = st.gsrc;
+        int n_pass;
+        asm volatile("s_mov_b32 %0, 2" : "=s"(n_pass));          // opaque trip count: the loop must stay a loop
+#pragma clang loop unroll(disable)
+        for (int pass = 0; pass < n_pass; ++pass) {
+            // (the store counters restart from 0 in every pass: under-counting only over-waits at the first boundaries)
+            st.pending = 0;
+            st.pending_prev = 0;
+            run_layer_pipe<PREC, NCH, SV, 1, 2, 0, 0>(cx, st, ha, hb, ha, &sigma_p);
+            run_layer_pipe<PREC, NCH, SV, 2, 3, 0, 1>(cx, st, hb, ha, hb, &sigma_p);
+            run_layer_pipe<PREC, NCH, SV, 3, 4, 0, 2>(cx, st, ha, hb, ha, &sigma_p);
+            if (pass == 0) {
+                run_layer_pipe<PREC, NCH, SV, 4, 5, 0, 3>(cx, st, hb, ha, hb, &sigma_p);        // skip layer: [xyz | h4] -> ha
+                // second pass = layers 5-7: everything the code addresses by layer index moves four layers on
+                constexpr int kDL = kLoopSecond - kLoopFirst;
+                st.gsrc = gsrc0 + (size_t)loop_chunk_shift(PREC) * kChunkBytes;
+                cx.bias_lane = bias0 + kDL * kPieceBytes;
+                if constexpr (SAVE) {
+                    cx.tile = tile_base + (F8 ? 8 * kDL * kPieceBytes : 16 * kDL * 64 * (int)sizeof(Slab));
+                    cx.gate_base = gate0 + kDL * kPieceBytes;
+                }
+                if constexpr (F8) cx.scale_base = scale0 + kDL * 4;
+            }
+        }
+        st.pending = 0;
+        st.pending_prev = 0;
+        st.gsrc = gsrc0;
+        cx.bias_lane = bias0;
+        cx.tile = tile_base;
+        cx.gate_base = gate0;
+        cx.scale_base = scale0;
+        // (h8 is in hb)
         // sigma head (tile 64, accumulator 0); finishes h8's last tile first
         run_layer_pipe<PREC, NCH, SV, 8, (SIGMA_ONLY ? -1 : 9), 0, 7>(cx, st, hb, nul, hb, &sigma_p);
         if constexpr (SIGMA_ONLY) {
@@ -649,6 +714,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
                 o.w = sigma_p;                                        // cat([rgb, sigma])   nerf.py:122
                 reinterpret_cast<float4*>(out)[po] = o;
             }
+#if NERFHIP_CLOCK_PROBE
+            if constexpr (F8) {
+                if (lane_o == 0) {
+                    unsigned* pr = reinterpret_cast<unsigned*>(tile_base + f8_act_scale_off() + 64);
+                    pr[0] = (unsigned)(clock64() - probe_c0);
+                    pr[1] = (unsigned)(wall_clock64() - probe_w0);
+                }
+            }
+#endif
             return;
         }
     }

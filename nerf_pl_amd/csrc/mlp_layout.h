@@ -71,12 +71,28 @@ constexpr int kParamOut[12] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 128,
 NH_HD constexpr int layer_slabs(int L) { return kLayers[L].enc_slabs + kLayers[L].chain_slabs; }
 // pieces per (slab, tile) fragment: bf16 = 1 (8 x bf16 per lane), fp32 = 2 (8 x f32 per lane)
 NH_HD constexpr int ppf(int prec) { return prec == 0 /*NERFHIP_F32*/ ? 2 : 1; }
-NH_HD constexpr int layer_pieces(int L, int prec) { return 1 + layer_slabs(L) * kLayers[L].nt * ppf(prec); }
-NH_HD constexpr int layer_start(int L, int prec) {
+// ---- the packed stream: per layer its nt * slabs A fragments (execution order); the 12 bias pieces (256 fp32 each, piece L =
+// bias of layer L) form one block between layers 4 and 5, padded to whole chunks.  The kernels copy the bias block into an LDS
+// image once and never read it from the ring.  Consequences the kernels rely on (static_asserts in mlp_fwd_kernel.h):
+//   * the 256 -> 256 layers are 128 (fp32: 256) pieces = whole chunks, so layers 1-3 and 5-7 see the chunk boundaries at the
+//     same steps;
+//   * the pad makes layer 5 start a multiple of kSlots chunks after layer 1, so both triples also use the same ring slots:
+//     one copy of the code of "three 256 -> 256 layers" serves both (a runtime loop; the unrolled network would not fit the
+//     64 KiB instruction cache).
+NH_HD constexpr int layer_pieces(int L, int prec) { return layer_slabs(L) * kLayers[L].nt * ppf(prec); }
+constexpr int kLoopFirst = 1, kLoopSecond = 5, kLoopLayers = 3;    // layers [1,4) and [5,8) share their code
+NH_HD constexpr int raw_start(int L, int prec) {                   // without the bias block
     int g = 0;
     for (int i = 0; i < L; ++i) g += layer_pieces(i, prec);
     return g;
 }
+NH_HD constexpr int bias_block_pieces(int prec) {                  // >= kNumLayers pieces, whole chunks, slot-aligning
+    int chunks = (kNumLayers + kChunkPieces - 1) / kChunkPieces;
+    while (((raw_start(kLoopSecond, prec) - raw_start(kLoopFirst, prec)) / kChunkPieces + chunks) % kSlots != 0) ++chunks;
+    return chunks * kChunkPieces;
+}
+NH_HD constexpr int bias_block_start(int prec) { return raw_start(kLoopSecond, prec); }
+NH_HD constexpr int layer_start(int L, int prec) { return raw_start(L, prec) + (L >= kLoopSecond ? bias_block_pieces(prec) : 0); }
 NH_HD constexpr int total_pieces(int prec) { return layer_start(kNumLayers, prec); }
 NH_HD constexpr int padded_pieces(int prec) {
     return (total_pieces(prec) + kChunkPieces - 1) / kChunkPieces * kChunkPieces;
@@ -84,6 +100,8 @@ NH_HD constexpr int padded_pieces(int prec) {
 NH_HD constexpr int chunks_upto_layer(int Lend, int prec) {   // chunks needed to run layers [0, Lend)
     return (layer_start(Lend, prec) + kChunkPieces - 1) / kChunkPieces;
 }
+// chunks between the two looped layer triples (a multiple of kSlots)
+NH_HD constexpr int loop_chunk_shift(int prec) { return (layer_start(kLoopSecond, prec) - layer_start(kLoopFirst, prec)) / kChunkPieces; }
 
 // ---- fragment order inside a layer: output-tile-major, fragment i = (tile i / nks, slab i % nks) -----------------------
 // (pack kernel and MLP kernels share these two functions)

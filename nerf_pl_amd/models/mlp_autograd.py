@@ -10,9 +10,9 @@ import torch
 from .. import ops
 
 
-def _param_grads(model, out, acts, dtype, g_out, workspace=None):
-    """nerfhip_mlp_bwd (chain + dW + reduce kernels) -> gradients in `flat_params()` order."""
-    packed_bwd = model.packed_weights_bwd(dtype)
+def _param_grads(model, out, acts, dtype, g_out, packed_bwd, workspace=None):
+    """nerfhip_mlp_bwd (chain + dW + reduce kernels) -> gradients in `flat_params()` order.  `packed_bwd`: the W^T image the
+    forward packed together with its own (NeRF.packed_weights_train)."""
     gw, gb, flat = ops.mlp_bwd(g_out, out, packed_bwd, acts, dtype, workspace=workspace)
     model._flat_grad = flat          # contiguous view of this step's gradients (parallel.GradSync / FlatAdam use it)
     hook = getattr(model, "_grad_ready_hook", None)
@@ -33,16 +33,17 @@ class _MLPRays(torch.autograd.Function):
     def forward(ctx, model, rays, z, *params):
         dtype = model.mlp_dtype
         acts = ops.alloc_acts(z.numel(), dtype, z.device)
-        out = ops.mlp_fwd_rays(rays, z, model.packed_weights(dtype), False, dtype, save=acts)
-        ctx.model, ctx.dtype, ctx.acts = model, dtype, acts
+        packed, packed_bwd = model.packed_weights_train(dtype)
+        out = ops.mlp_fwd_rays(rays, z, packed, False, dtype, save=acts)
+        ctx.model, ctx.dtype, ctx.acts, ctx.packed_bwd = model, dtype, acts, packed_bwd
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         (out,) = ctx.saved_tensors
-        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out)
-        ctx.acts = None
+        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, ctx.packed_bwd)
+        ctx.acts = ctx.packed_bwd = None
         return (None, None, None) + tuple(grads)
 
 
@@ -53,8 +54,9 @@ class _MLPEmbedded(torch.autograd.Function):
     def forward(ctx, model, x, *params):
         dtype = model.mlp_dtype
         acts = ops.alloc_acts(x.shape[0], dtype, x.device)
-        out = ops.mlp_fwd_embedded(x, model.packed_weights(dtype), False, dtype, save=acts)
-        ctx.model, ctx.dtype, ctx.acts = model, dtype, acts
+        packed, packed_bwd = model.packed_weights_train(dtype)
+        out = ops.mlp_fwd_embedded(x, packed, False, dtype, save=acts)
+        ctx.model, ctx.dtype, ctx.acts, ctx.packed_bwd = model, dtype, acts, packed_bwd
         ctx.save_for_backward(out)
         return out
 
@@ -62,8 +64,8 @@ class _MLPEmbedded(torch.autograd.Function):
     def backward(ctx, g_out):
         (out,) = ctx.saved_tensors
         ws = {} if ctx.needs_input_grad[1] else None
-        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, workspace=ws)
-        ctx.acts = None
+        grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, ctx.packed_bwd, workspace=ws)
+        ctx.acts = ctx.packed_bwd = None
         gx = None
         if ctx.needs_input_grad[1]:          # nerf.py:100-124 is differentiable w.r.t. x: dx from the chain's dY slabs
             m = ctx.model

@@ -112,15 +112,34 @@ class NeRF(nn.Module):
         ops.pack_weights_raw(wp, bp, buf, dtype)
         return buf
 
+    def _bwd_buffer(self, dtype, dev):
+        buf = self._packed_cache.get(("bwd", dtype))
+        if buf is None or buf.device != dev:
+            buf = self._packed_cache[("bwd", dtype)] = torch.empty(ops.packed_bwd_bytes(dtype), device=dev, dtype=torch.uint8)
+        return buf
+
     def packed_weights_bwd(self, dtype=None):
         """W^T stream for the backward chain (same policy as packed_weights)."""
         dtype = dtype or self.mlp_dtype
         wp, _, dev = self._pack_args()
-        buf = self._packed_cache.get(("bwd", dtype))
-        if buf is None or buf.device != dev:
-            buf = self._packed_cache[("bwd", dtype)] = torch.empty(ops.packed_bwd_bytes(dtype), device=dev, dtype=torch.uint8)
+        buf = self._bwd_buffer(dtype, dev)
         ops.pack_weights_bwd_raw(wp, buf, dtype)
         return buf
+
+    def packed_weights_train(self, dtype=None):
+        """(forward image, W^T image) of the current parameters in ONE launch: a training forward packs both, its backward
+        (same weights: autograd forbids changing them in between) reuses the second."""
+        if not self.is_default_arch():
+            raise NotImplementedError("the fused HIP MLP implements the reference's default architecture "
+                                      "(D=8, W=256, skips=[4], 63/27 inputs) only")
+        dtype = dtype or self.mlp_dtype
+        wp, bp, dev = self._pack_args()
+        buf = self._packed_cache.get(dtype)
+        if buf is None or buf.device != dev:
+            buf = self._packed_cache[dtype] = torch.empty(ops.packed_bytes(dtype), device=dev, dtype=torch.uint8)
+        bwd = self._bwd_buffer(dtype, dev)
+        ops.pack_weights_train_raw(wp, bp, buf, bwd, dtype)
+        return buf, bwd
 
     def forward(self, x, sigma_only=False):
         """x: (B, 63+27) embedded position+direction, or (B, 63) when sigma_only.

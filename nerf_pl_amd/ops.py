@@ -221,12 +221,18 @@ class _MsePsnr(torch.autograd.Function):
               "nerfhip_mse_psnr")
         ctx.save_for_backward(g_c, g_f)
         ctx.mark_non_differentiable(out3)
+        ctx.set_materialize_grads(False)      # no zeros(3) launch for the unused gradient of out3
         return out3[0], out3
 
     @staticmethod
     def backward(ctx, g_loss, _g_out3):
         g_c, g_f = ctx.saved_tensors
-        return g_c * g_loss, (g_f * g_loss if g_f is not None else None), None
+        if g_loss is None:
+            return None, None, None
+        if g_f is None:
+            return g_c * g_loss, None, None
+        g_c, g_f = torch._foreach_mul([g_c, g_f], g_loss)      # one launch for both images
+        return g_c, g_f, None
 
 
 @device_guard
@@ -303,6 +309,12 @@ def pack_weights_raw(wp, bp, out, dtype):
 def pack_weights_bwd_raw(wp, out, dtype):
     check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), mlp_dtype_code(dtype), stream_ptr()),
           "nerfhip_mlp_pack_weights_bwd")
+
+
+@device_guard
+def pack_weights_train_raw(wp, bp, out, out_bwd, dtype):
+    check(_lib.load().nerfhip_mlp_pack_weights_train(wp, bp, ptr(out), ptr(out_bwd), mlp_dtype_code(dtype), stream_ptr()),
+          "nerfhip_mlp_pack_weights_train")
 
 
 def alloc_acts(n_points, dtype, device):

@@ -482,3 +482,36 @@ def test_graphed_step_recaptures_on_lr_change(dev):
     stepper(batch)
     assert stepper.graph is not g0 and stepper.captured_lr == 2.5e-4
     assert not torch.equal(system.nerf_fine.sigma.weight.detach(), w0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_f8"])
+def test_pack_weights_train_equals_separate_packs(dev, dtype):
+    """nerfhip_mlp_pack_weights_train (forward + W^T image in one launch, what a training forward uses) writes byte for
+    byte what nerfhip_mlp_pack_weights and nerfhip_mlp_pack_weights_bwd write."""
+    from nerf_pl_amd.models.nerf import NeRF
+    m = NeRF()
+    m.load_state_dict(O.make_params(11, 4.0, 0.2))
+    m = m.to(dev)
+    fwd = m.packed_weights(dtype).clone()
+    bwd = m.packed_weights_bwd(dtype).clone()
+    m._packed_cache.pop(dtype), m._packed_cache.pop(("bwd", dtype))        # fresh (uninitialised) buffers
+    f2, b2 = m.packed_weights_train(dtype)
+    assert torch.equal(fwd, f2) and torch.equal(bwd, b2)
+
+
+def test_loss_backward_scales_with_upstream_gradient(dev):
+    """MSELoss backward honours the gradient flowing into the loss (loss scaling), through its single fused multiply."""
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    c = torch.rand(64, 3, generator=g).to(dev).requires_grad_(True)
+    f = torch.rand(64, 3, generator=g).to(dev).requires_grad_(True)
+    t = torch.rand(64, 3, generator=g).to(dev)
+    loss, _ = ops.mse_psnr(c, f, t)
+    (loss * 0.25).backward()
+    ref_c = 0.25 * 2 * (c.detach() - t) / t.numel()
+    ref_f = 0.25 * 2 * (f.detach() - t) / t.numel()
+    assert torch.allclose(c.grad, ref_c, rtol=1e-6, atol=1e-9) and torch.allclose(f.grad, ref_f, rtol=1e-6, atol=1e-9)
+    c2 = c.detach().clone().requires_grad_(True)
+    loss2, _ = ops.mse_psnr(c2, None, t)                      # coarse-only (N_importance = 0)
+    loss2.backward()
+    assert torch.allclose(c2.grad, 2 * (c2.detach() - t) / t.numel(), rtol=1e-6, atol=1e-9)

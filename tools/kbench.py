@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--interleaved", action="store_true")
+    ap.add_argument("--clock-probe", action="store_true",
+                    help="library built with -DNERFHIP_CLOCK_PROBE=1, --dtype bf16_f8: shader clock and cycles of the saving forward")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = NeRF()
@@ -77,6 +79,17 @@ def main():
                 for i in range(len(fns)):
                     tot[i] += evs[i].elapsed_time(evs[i + 1]) * 1e3
         print("   interleaved (step order): " + "  ".join("%s %.1f" % (n, t / a.reps) for n, t in zip(names, tot)), flush=True)
+    if a.clock_probe and a.dtype == "bf16_f8":
+        for _ in range(10):
+            ops.mlp_fwd_rays(rays, z, packed, False, a.dtype, save=acts)
+        torch.cuda.synchronize()
+        tiles = ((B * S + 255) // 256) * 8
+        tb = acts.numel() // tiles
+        pr = acts.view(tiles, tb)[:, (79 + 9) * 1024 + 64:(79 + 9) * 1024 + 72].contiguous().view(torch.int32).double()
+        cyc, wall = pr[:, 0], pr[:, 1]
+        print("   clock probe (fwd+save): %.0f kcycles/wave (min %.0f max %.0f), %.1f us/wave, shader clock %.0f MHz"
+              % (cyc.mean().item() / 1e3, cyc.min().item() / 1e3, cyc.max().item() / 1e3, wall.mean().item() / 100.0,
+                 (cyc.sum() / wall.sum()).item() * 100.0), flush=True)
     print("%s %dx%d %s: fwd %.1f (min %.1f)  fwd_sigma %.1f  fwd+save %.1f (min %.1f)  bwd %.1f (min %.1f) = chain %.1f + dW %.1f + reduce %.1f us"
           % (os.path.basename(os.environ.get("NERFHIP_LIB_PATH", "libnerfhip.so")), B, S, a.dtype, f_avg, f_min, so_avg, s_avg, s_min,
              b_avg, b_min, ph[0][0], ph[1][0], ph[2][0]), flush=True)
