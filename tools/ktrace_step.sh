@@ -4,7 +4,7 @@
 TAG=$1; shift
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/bench_under_trace.json 2> $OUT/trace.log
+timeout 240 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/bench_under_trace.json 2> $OUT/trace.log
 cd $REPO
 python - <<PY
 import csv, collections

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for D in $DTYPES; do
   for S in 192 64; do
     for C in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/pmc_${D}_${S}_$C -o p -- python $REPO/tools/kbench.py --dtype $D --samples $S --reps 2 > /dev/null 2> $OUT/pmc_${D}_${S}_$C.log
+      timeout 150 rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/pmc_${D}_${S}_$C -o p -- python $REPO/tools/kbench.py --dtype $D --samples $S --reps 2 > /dev/null 2> $OUT/pmc_${D}_${S}_$C.log
     done
   done
 done

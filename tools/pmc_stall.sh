@@ -25,7 +25,7 @@ CGRP=(
 )
 i=0
 for G in "${CGRP[@]}"; do
-  rocprofv3 --pmc $G --kernel-trace -f csv -d $OUT/g$i -o p -- python $REPO/tools/kbench.py --dtype $D --reps 2 > /dev/null 2> $OUT/g$i.log || echo "group $i failed: $G" >> $OUT/failed.txt
+  timeout 90 rocprofv3 --pmc $G --kernel-trace -f csv -d $OUT/g$i -o p -- python $REPO/tools/kbench.py --dtype $D --reps 2 > /dev/null 2> $OUT/g$i.log || echo "group $i failed: $G" >> $OUT/failed.txt
   i=$((i+1))
 done
 cd $REPO
