@@ -822,7 +822,10 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
     return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
 }
 
-// NERFHIP_DW_WGS / 12 splits per job (fewer for few tiles)
+// NERFHIP_DW_WGS / 12 splits per job (fewer for few tiles): EQUAL ring-iteration counts per workgroup.  Under load every
+// workgroup completes one stage per (loaded HBM latency / stages in flight) whatever the stage's size, so a workgroup's time
+// follows its iteration count, not its bytes — splits in proportion to the jobs' bytes (5 to 18 slab pairs per tile) measured
+// 306 / 290 / 268 us at 512 / 768 / 1024 workgroups against 225-232 us for this plan (1024 x 192 points).
 static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
     using namespace nerfhip::mlp;
     const int64_t tiles = act_tiles(n_points, dtype) / (dtype == NERFHIP_BF16_F8 ? 2 : 1);   // f8: units of work are tile PAIRS
