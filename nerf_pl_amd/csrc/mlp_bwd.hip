@@ -12,6 +12,7 @@
 //     accumulators in registers for the whole range, one partial slab per workgroup; mlp_bwd_reduce sums
 //     the slabs, un-permutes features and writes the (out,in) gradient tensors + biases.
 //     HBM-bound by construction: 2*256*256 FLOP per 2*256*2 B = 128 FLOP/B.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -379,7 +380,7 @@ struct DwJobTable {
 #define NERFHIP_DW_DEPTH 4
 #endif
 #ifndef NERFHIP_DW_WGS
-#define NERFHIP_DW_WGS 512       // target workgroup count of the dW launch (2 rounds of 256 CUs at 1 workgroup/CU)
+#define NERFHIP_DW_WGS 512       // target workgroup count of the bf16 / fp32 dW launch (2 rounds of 256 CUs at 1 workgroup/CU)
 #endif
 
 template <int PREC> struct DwTraits;
@@ -826,12 +827,26 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 // workgroup completes one stage per (loaded HBM latency / stages in flight) whatever the stage's size, so a workgroup's time
 // follows its iteration count, not its bytes — splits in proportion to the jobs' bytes (5 to 18 slab pairs per tile) measured
 // 306 / 290 / 268 us at 512 / 768 / 1024 workgroups against 225-232 us for this plan (1024 x 192 points).
+// e4m3 kernel: ONE round of the 256 CUs (measured at 1024 x 192: 207-215 us vs 233-247 us for 384-768 workgroups, and half the
+// split-K partials for the reduce kernel: 23 -> 12.5 us); the bf16 kernel does not care (440 us either way), the fp32 one
+// prefers two rounds (2,882 vs 3,244 us).
+#ifndef NERFHIP_DWF8_WGS
+#define NERFHIP_DWF8_WGS 256
+#endif
+static int dw_target_wgs(int dtype) {
+    static const int env = [] {
+        const char* e = getenv("NERFHIP_DW_WGS");            // experiments only
+        return e ? atoi(e) : 0;
+    }();
+    return env > 0 ? env : (dtype == NERFHIP_BF16_F8 ? NERFHIP_DWF8_WGS : NERFHIP_DW_WGS);
+}
 static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
     using namespace nerfhip::mlp;
     const int64_t tiles = act_tiles(n_points, dtype) / (dtype == NERFHIP_BF16_F8 ? 2 : 1);   // f8: units of work are tile PAIRS
     int off = 0;
     for (int j = 0; j < kNumDwJobs; ++j) {
-        int64_t ns = NERFHIP_DW_WGS / kNumDwJobs;
+        const int target = dw_target_wgs(dtype);
+        int64_t ns = target / kNumDwJobs + (j >= 1 && j <= target % kNumDwJobs ? 1 : 0);   // remainder: to the 256 x 256 jobs
 #ifndef NERFHIP_DW_MIN_ITERS
 #define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
 #endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
