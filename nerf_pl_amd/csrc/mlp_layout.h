@@ -102,6 +102,13 @@ NH_HD constexpr int chunks_upto_layer(int Lend, int prec) {   // chunks needed t
 }
 // chunks between the two looped layer triples (a multiple of kSlots)
 NH_HD constexpr int loop_chunk_shift(int prec) { return (layer_start(kLoopSecond, prec) - layer_start(kLoopFirst, prec)) / kChunkPieces; }
+static_assert(layer_start(kLoopFirst, 0) % kChunkPieces == 0 && layer_start(kLoopFirst, 1) % kChunkPieces == 0 &&
+                  layer_start(kLoopSecond, 0) % kChunkPieces == 0 && layer_start(kLoopSecond, 1) % kChunkPieces == 0,
+              "the looped layer triples start on chunk boundaries");
+static_assert(loop_chunk_shift(0) % kSlots == 0 && loop_chunk_shift(1) % kSlots == 0, "... in the same ring slots");
+static_assert(bias_block_pieces(0) >= kNumLayers && bias_block_pieces(1) >= kNumLayers, "the bias block holds every layer's bias");
+static_assert(layer_pieces(kLoopFirst, 1) == layer_pieces(kLoopSecond, 1) && layer_pieces(kLoopFirst + 2, 1) == layer_pieces(kLoopSecond + 2, 1),
+              "the triples are layer-for-layer the same shape");
 
 // ---- fragment order inside a layer: output-tile-major, fragment i = (tile i / nks, slab i % nks) -----------------------
 // (pack kernel and MLP kernels share these two functions)
