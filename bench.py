@@ -305,7 +305,11 @@ def main():
     # The training step (fwd, loss, bwd, [all-reduce], Adam: ~40 launches) is replayed as ONE hipGraph after 3 eager
     # steps; same work per step, ~15 us of host time instead of ~1.5 ms.  Falls back to eager issue if capture fails.
     def make_stepper(system_, opt_, sync_):
-        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3) if not a.no_graph else None}
+        # fresh batches are drawn INSIDE the graph (RayStore.sample with the default generator: randint + gen_rays + gather are
+        # captured, torch's graph-safe Philox state advances per replay): no per-step copies into static buffers
+        in_graph = not a.fixed_batch
+        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=(lambda: store.sample(B)) if in_graph else None)
+              if not a.no_graph else None}
 
         def eager(batch):
             out = system_.training_step(batch, 0)
@@ -317,17 +321,16 @@ def main():
             return out
 
         def step_():
-            batch = next_batch()
             g = st["graphed"]
             if g is None:
-                return eager(batch)
+                return eager(next_batch())
             try:
-                return g(batch)
+                return g() if g.batch_source is not None else g(next_batch())
             except Exception as e:  # noqa: BLE001 - capture problems must not kill the benchmark
                 print("[bench] hipGraph capture failed (%s: %s); continuing eagerly" % (type(e).__name__, e), file=sys.stderr, flush=True)
                 st["graphed"] = None
                 torch.cuda.synchronize()
-                return eager(batch)
+                return eager(next_batch())
         return step_, st
 
     train_step, state = make_stepper(system, opt, grad_sync)
@@ -454,7 +457,8 @@ def main():
                        "mlp_dtype": a.dtype,
                        "rays_per_gpu": (a.image_rays // world if a.mode == "eval" else B), "N_samples": S, "N_importance": N,
                        "batches": ("one resident batch replayed" if (a.fixed_batch or a.mode != "train") else
-                                   "fresh RayStore.sample(%d) per step inside the timed loop (pixel ids -> rays on the GPU)" % B),
+                                   "fresh RayStore.sample(%d) per step inside the timed loop (pixel ids -> rays on the GPU%s)"
+                                   % (B, ", captured in the step's hipGraph" if not a.no_graph else "")),
                        "issue": ("hipGraph replay of the whole step" if (a.mode == "train" and state["graphed"] is not None
                                                                          and state["graphed"].graph is not None)
                                  else "hipGraph replay per 32768-ray chunk" if a.mode == "eval" else "eager"),

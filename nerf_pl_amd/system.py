@@ -174,8 +174,12 @@ class GraphedTrainStep:
     exercised at world size 1 here).
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
-    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False, backend=None):
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False, backend=None, batch_source=None):
         self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
+        # `batch_source`: a callable returning the next {'rays', 'rgbs'} batch from device-resident data (RayStore.sample with
+        # the default generator).  It is then called INSIDE the step, i.e. captured into the graph: every replay draws a fresh
+        # batch (torch's graph-safe Philox state advances per replay) and no batch is copied into static buffers.
+        self.batch_source = batch_source
         self.warmup = warmup
         self.sync_in_graph = sync_in_graph
         self.calls = 0
@@ -198,6 +202,8 @@ class GraphedTrainStep:
         return d(out)
 
     def _fwd_bwd(self, batch):
+        if self.batch_source is not None:
+            batch = self.batch_source()
         out = self.system.training_step(batch, self.calls)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
@@ -218,7 +224,7 @@ class GraphedTrainStep:
             self.grad_sync.hooks_enabled = on
 
     def _capture(self, batch):
-        self.static_batch = {k: v.clone() for k, v in batch.items()}
+        self.static_batch = {k: v.clone() for k, v in batch.items()} if batch is not None else None
         self.captured_lr = get_learning_rate(self.opt)
         self.static_out = None
         self.graph_opt = None
@@ -236,14 +242,16 @@ class GraphedTrainStep:
             finally:
                 self._set_hooks(True)
 
-    def __call__(self, batch):
+    def __call__(self, batch=None):
+        if (batch is None) != (self.batch_source is not None):
+            raise ValueError("pass a batch, or construct the stepper with a batch_source (not both)")
         self.calls += 1
         if self.calls <= self.warmup:
             return self.backend.on_side_stream(self._eager, batch)
         if (self.graph is None or get_learning_rate(self.opt) != self.captured_lr
-                or any(batch[k].shape != self.static_batch[k].shape for k in batch)):
+                or (batch is not None and any(batch[k].shape != self.static_batch[k].shape for k in batch))):
             self._capture(batch)
-        else:
+        elif batch is not None:
             for k, v in batch.items():
                 self.static_batch[k].copy_(v, non_blocking=True)
         self.graph.replay()

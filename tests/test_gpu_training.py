@@ -515,3 +515,41 @@ def test_loss_backward_scales_with_upstream_gradient(dev):
     loss2, _ = ops.mse_psnr(c2, None, t)                      # coarse-only (N_importance = 0)
     loss2.backward()
     assert torch.allclose(c2.grad, 2 * (c2.detach() - t) / t.numel(), rtol=1e-6, atol=1e-9)
+
+
+def test_graphed_step_draws_a_fresh_batch_every_replay(dev):
+    """GraphedTrainStep(batch_source=RayStore.sample): the batch is drawn INSIDE the captured step (randint + gen_rays + gather),
+    and every replay draws a different one (torch's graph-safe Philox state advances per replay)."""
+    from argparse import Namespace
+    from nerf_pl_amd.rays import RayStore
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    hp = Namespace(N_samples=16, N_importance=16, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32,
+                   loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True)
+    system = NeRFSystem(hp)
+    system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+    system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
+    for m in system.models:
+        m.mlp_dtype = "bf16_f8"
+    system = system.to(dev)
+    (opt,), _ = system.configure_optimizers()
+    g = torch.Generator().manual_seed(0)
+    poses = torch.eye(4)[:3].repeat(3, 1, 1)
+    poses[:, 2, 3] = torch.tensor([4.0, 4.2, 3.8])
+    store = RayStore(poses.to(dev), torch.rand(3, 32, 32, 3, generator=g).to(dev), 32, 32, 40.0, 2.0, 6.0)
+    seen = {}
+
+    def source():
+        b = store.sample(64)
+        seen["rays"] = b["rays"]           # after capture: the graph's own tensor, rewritten by every replay
+        return b
+    stepper = GraphedTrainStep(system, opt, warmup=2, batch_source=source)
+    drawn, losses = [], []
+    for _ in range(7):
+        losses.append(stepper()["loss"].item())
+        drawn.append(seen["rays"].clone())
+    assert stepper.graph is not None
+    for i in range(3, 7):                  # replays (calls 4..7): each differs from the one before
+        assert not torch.equal(drawn[i], drawn[i - 1]), i
+    assert all(torch.isfinite(torch.tensor(losses)))
+    with pytest.raises(ValueError):
+        stepper({"rays": drawn[0], "rgbs": torch.zeros(64, 3, device=dev)})
