@@ -180,6 +180,7 @@ class GraphedTrainStep:
         # the default generator).  It is then called INSIDE the step, i.e. captured into the graph: every replay draws a fresh
         # batch (torch's graph-safe Philox state advances per replay) and no batch is copied into static buffers.
         self.batch_source = batch_source
+        self._seed = None
         self.warmup = warmup
         self.sync_in_graph = sync_in_graph
         self.calls = 0
@@ -206,7 +207,9 @@ class GraphedTrainStep:
             batch = self.batch_source()
         out = self.system.training_step(batch, self.calls)
         self.opt.zero_grad(set_to_none=True)
-        out['loss'].backward()
+        if self._seed is None:                 # created in an eager warm-up step, reused by every later (captured) one:
+            self._seed = torch.ones_like(out['loss'])        # spares the ones_like fill launch of a bare .backward()
+        out['loss'].backward(self._seed)
         return self._detached(out)
 
     def _eager(self, batch):
