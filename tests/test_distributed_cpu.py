@@ -217,3 +217,30 @@ def test_single_process_passthrough():
     out = parallel.render_sharded(_fake_render, rays, keys=("rgb_fine",))
     assert torch.equal(out["rgb_fine"], _fake_render(rays)["rgb_fine"])
     parallel.GradSync([_Tiny()]).sync()     # no process group: no-op
+
+
+def test_graphed_step_batch_source_host_logic():
+    """GraphedTrainStep(batch_source=...): the source is called inside every eager step and inside every replay (i.e. inside
+    the captured region), never at capture time, and mixing it with an explicit batch is refused."""
+    from nerf_pl_amd.system import GraphedTrainStep
+    sysm = _TinySystem()
+    opt = torch.optim.SGD(sysm.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(3)
+    calls = []
+
+    def source():
+        calls.append(len(calls))
+        return {"x": torch.randn(16, 5, generator=g), "y": torch.randn(16, 3, generator=g)}
+    be = _RecordingBackend()
+    stepper = GraphedTrainStep(sysm, opt, warmup=2, backend=be, batch_source=source)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in sysm.parameters()])
+    for _ in range(5):
+        stepper()
+    assert be.captures == 1 and stepper.graph.replays == 3
+    assert len(calls) == 5                                  # 2 eager + 3 replays; the capture itself ran nothing
+    after = torch.cat([p.detach().reshape(-1) for p in sysm.parameters()])
+    assert not torch.equal(before, after)
+    with pytest.raises(ValueError):
+        stepper({"x": torch.zeros(16, 5), "y": torch.zeros(16, 3)})
+    with pytest.raises(ValueError):
+        GraphedTrainStep(sysm, opt, warmup=2, backend=_RecordingBackend())()
