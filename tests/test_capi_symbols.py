@@ -103,3 +103,22 @@ def test_install_registers_reference_module_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/nerfhip.h is the boundary a non-Python host binds: it must compile as strict C99 (and as C++), and a C program
+    referencing every declared entry point must link against libnerfhip.so (no GPU needed: nothing is called)."""
+    from nerf_pl_amd import _lib
+    src = tmp_path / "use_all.c"
+    body = "\n".join("    p[%d] = (void (*)(void))%s;" % (i, s) for i, s in enumerate(_header_symbols()))
+    src.write_text('#include "nerfhip.h"\nint main(void) {\n    void (*p[%d])(void);\n%s\n    return p[0] == 0;\n}\n'
+                   % (len(_header_symbols()), body))
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-Wno-pedantic", "-I", inc, "-c", str(src),
+                    "-o", str(tmp_path / "use_all.o")], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "use_all_cc.o")],
+                   check=True)
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    hip = "/opt/rocm/lib"
+    subprocess.run(["gcc", str(tmp_path / "use_all.o"), "-o", str(tmp_path / "use_all"), "-L", libdir, "-lnerfhip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath," + hip, "-L", hip, "-lamdhip64"], check=True)
