@@ -407,6 +407,11 @@ def main():
               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
               "traffic": traffic_db.get("mlp_fwd_kernel|%s|%d" % (a.dtype, B * (S + N)), {}).get("hbm_bytes_per_launch"),
               "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min_us, 2)}
+        if a.dtype != "fp32":
+            # informational: what this chip sustains at all under back-to-back bf16 MFMAs (it is power-limited: the shader
+            # clock settles at 1.45-1.83 GHz), measured by tools/probes/probe_mfma_rate.hip -> profiles/r02_probe_mfma_rate.txt
+            ns["measured_ceiling"] = {"bare_mfma_frac_of_peak": [0.61, 0.66], "this_instruction_mix_frac_of_peak": [0.57, 0.59],
+                                      "source": "profiles/r02_probe_mfma_rate.txt"}
         if a.mode == "train":
             # ---- the kernels the TIMED step runs, one entry each; `roofline` = the one that takes the most time ----
             table = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db)
