@@ -79,9 +79,13 @@ class GraphRenderer:
             m.packed_weights()          # repack into the same device buffers the captured graph reads
 
     def _capture(self):
+        with torch.cuda.device(self.rays.device):       # streams and the graph belong to the GPU that owns the buffers
+            self._capture_on_device()
+
+    def _capture_on_device(self):
         self._pack()
         S, N, disp, wb = self.cfg
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream(device=self.rays.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(side):
             for _ in range(2):           # warm-up outside capture (module load, allocator pools)
@@ -97,12 +101,13 @@ class GraphRenderer:
         n = rays.shape[0]
         if n > self.chunk:
             raise ValueError("chunk larger than the captured shape")
-        self._pack()
-        self.rays[:n].copy_(rays)
-        if n < self.chunk:
-            self.rays[n:].copy_(rays[n - 1:n].expand(self.chunk - n, 8))
-        self.graph.replay()
-        return {k: v[:n].clone() for k, v in self.out.items()}
+        with torch.cuda.device(self.rays.device):
+            self._pack()
+            self.rays[:n].copy_(rays)
+            if n < self.chunk:
+                self.rays[n:].copy_(rays[n - 1:n].expand(self.chunk - n, 8))
+            self.graph.replay()
+            return {k: v[:n].clone() for k, v in self.out.items()}
 
     @torch.no_grad()
     def render_to_host(self, rays, keys=("rgb_fine", "depth_fine")):
@@ -112,11 +117,15 @@ class GraphRenderer:
         Compute stream: replay chunk i, then copy its outputs into slice i of a device-side image buffer (the graph's
         static outputs are overwritten by the next replay; the slice is not) and record an event.  Copy stream: wait for
         that event, DMA the slice into the pinned buffer.  Only the last chunk's copy is exposed."""
+        with torch.cuda.device(self.rays.device):       # current stream / copy stream of the GPU that owns the buffers
+            return self._render_to_host(rays, keys)
+
+    def _render_to_host(self, rays, keys):
         n = rays.shape[0]
         dev = self.rays.device
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(dev)
         if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream()
+            self._copy_stream = torch.cuda.Stream(device=dev)
         img = {k: torch.empty((n,) + tuple(self.out[k].shape[1:]), device=dev, dtype=torch.float32) for k in keys}
         host = {k: torch.empty(v.shape, dtype=torch.float32, pin_memory=True) for k, v in img.items()}
         self._pack()

@@ -67,7 +67,7 @@ class GradSync:
         self.overlap = overlap
         self.hooks_enabled = True   # GraphedTrainStep switches the hooks off while it captures/replays a graph that
                                     # must not contain the collective (two-graph mode)
-        self._inflight = {}         # id(model) -> (work, flat)
+        self._inflight = {}         # id(model) -> [(work, flat, needs_division)] issued from the hook since the last sync()
         self.started_early = 0      # statistics: all-reduces issued from the hook (tests assert on it)
         if overlap:
             self.attach()
@@ -93,11 +93,36 @@ class GradSync:
         return dist.ReduceOp.SUM, True
 
     def _on_grad_ready(self, model, flat):
+        """Called by the fused backward when `flat` (the model's 24 gradients) is complete, BEFORE autograd hands the views
+        to the parameters.  The all-reduce is started here only when autograd is going to adopt the views as `p.grad`
+        (every `p.grad` is None: zero_grad(set_to_none=True), no accumulation): otherwise autograd would accumulate the views
+        into existing `.grad` tensors on the compute stream while the collective rewrites `flat` on the communicator's."""
         if not (self.hooks_enabled and self.overlap and self.active()):
             return
+        # a second backward before sync(): its accumulation into p.grad (views of the first buffer) must be ordered after
+        # the collective that is still rewriting that buffer — finish (wait, divide) what is in flight for this model
+        self._finish(self._inflight.get(id(model), ()))
+        if any(p.grad is not None for p in model.parameters()):
+            return                                     # gradient accumulation: sync() reduces the accumulated p.grad
         op, div = self._avg_op()
-        self._inflight[id(model)] = (dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, div)
+        work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        self._inflight.setdefault(id(model), []).append([work, flat, div, False])
         self.started_early += 1
+
+    def _finish(self, entries):
+        """wait for hook-issued collectives and apply their division: afterwards each buffer holds the rank average"""
+        for e in entries:
+            if not e[3]:
+                e[0].wait()
+                if e[2]:
+                    e[1].div_(dist.get_world_size(self.group))
+                e[3] = True
+
+    @staticmethod
+    def _aliases(params, flat):
+        """autograd adopted the views of `flat` as the parameters' .grad (first and last parameter checked)"""
+        sp = flat.untyped_storage().data_ptr()
+        return (params[0].grad.untyped_storage().data_ptr() == sp and params[-1].grad.untyped_storage().data_ptr() == sp)
 
     # -- the step-level call ----------------------------------------------------------------------------------------
     def sync(self):
@@ -109,13 +134,23 @@ class GradSync:
         works = []
         for m in self.models:
             flat = getattr(m, "_flat_grad", None)
-            early = self._inflight.pop(id(m), None)
-            if early is not None and flat is not None and early[1].data_ptr() == flat.data_ptr():
-                works.append((early[0], flat, None, early[2]))
-                continue
+            early = self._inflight.pop(id(m), [])
             params = [p for p in m.parameters() if p.grad is not None]
-            if (flat is not None and params and params[0].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
-                    and params[-1].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()):
+            if (len(early) == 1 and not early[0][3] and flat is not None and early[0][1] is flat and params
+                    and self._aliases(params, flat)):
+                works.append((early[0][0], flat, None, early[0][2]))        # the overlapped collective IS the gradient
+                continue
+            # early collectives whose buffer is not simply p.grad: finish them, then reduce p.grad.  If p.grad still views
+            # that buffer (a later backward accumulated on top of the averaged values) averaging again is exact — the
+            # averaged part is identical on every rank; if autograd COPIED the views instead of adopting them, the copy
+            # raced with the collective and p.grad is undefined: refuse.
+            self._finish(early)
+            for _, eflat, _, _ in early:
+                if params and not self._aliases(params, eflat):
+                    raise RuntimeError("GradSync: the gradient buffer all-reduced from the grad-ready hook was not adopted as "
+                                       "p.grad (autograd copied it while the collective was in flight); construct "
+                                       "GradSync(overlap=False) for this training loop")
+            if flat is not None and params and self._aliases(params, flat) and not early:
                 works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, None, div))
             elif params:
                 buf = torch.cat([p.grad.reshape(-1) for p in params])

@@ -73,7 +73,8 @@ class RayStore:
     (blender.py:81-84); `image_rays(i)` the (H*W, 8) rays of one image (validation / eval)."""
 
     def __init__(self, poses, rgbs, H, W, focal, near, far, use_ndc=False, ndc_near_plane=1.0):
-        require_gpu(poses, rgbs)
+        with torch.cuda.device(poses.device if poses.is_cuda else torch.cuda.current_device()):
+            require_gpu(poses, rgbs)
         self.poses = poses.contiguous()
         self.rgbs = rgbs.reshape(-1, 3).contiguous()
         self.H, self.W, self.focal, self.near, self.far = int(H), int(W), float(focal), float(near), float(far)

@@ -153,25 +153,77 @@ def _worker(rank, world, port, n_rays, q):
         # all-reduce is issued THEN (while "the rest of backward" still runs) and sync() only waits and averages
         m3 = _Tiny()
         gs = parallel.GradSync([m3])
-        flat3 = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) + 1.0
-        off = 0
-        for p, sz in zip(m3.parameters(), sizes):
-            p.grad = flat3[off:off + sz].view_as(p)
-            off += sz
+        base3 = torch.arange(sum(sizes), dtype=torch.float32)
+
+        def adopt(model, flat_):                            # what autograd does with the views the backward returns
+            off_ = 0
+            for p_, sz_ in zip(model.parameters(), sizes):
+                p_.grad = flat_[off_:off_ + sz_].view_as(p_)
+                off_ += sz_
+        flat3 = base3 * (rank + 1) + 1.0
         m3._flat_grad = flat3
         assert m3._grad_ready_hook is not None
-        m3._grad_ready_hook(m3, flat3)                      # what models/mlp_autograd._param_grads does
+        m3._grad_ready_hook(m3, flat3)                      # what models/mlp_autograd._param_grads does (p.grad still None)
+        adopt(m3, flat3)
         started = gs.started_early
         gs.sync()
-        ok_overlap = started == 1 and not gs._inflight and torch.allclose(
-            flat3, torch.arange(sum(sizes), dtype=torch.float32) * want + 1.0)
+        ok_overlap = started == 1 and not gs._inflight and torch.allclose(flat3, base3 * want + 1.0)
         # hooks switched off (two-graph capture): nothing is issued early, sync() does the whole job
         gs.hooks_enabled = False
-        flat3.copy_(torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1))
+        for p_ in m3.parameters():
+            p_.grad = None
+        flat3.copy_(base3 * (rank + 1))
         m3._grad_ready_hook(m3, flat3)
+        adopt(m3, flat3)
         ok_overlap = ok_overlap and gs.started_early == 1
         gs.sync()
-        ok_overlap = ok_overlap and torch.allclose(flat3, torch.arange(sum(sizes), dtype=torch.float32) * want)
+        ok_overlap = ok_overlap and torch.allclose(flat3, base3 * want)
+        gs.hooks_enabled = True
+        # gradient accumulation: p.grad exists when the backward announces its buffer -> autograd ACCUMULATES the
+        # views into p.grad, so no early collective may touch the buffer; sync() averages the accumulated p.grad
+        acc = [torch.full_like(p_, 10.0 * (rank + 1)) for p_ in m3.parameters()]
+        for p_, a_ in zip(m3.parameters(), acc):
+            p_.grad = a_.clone()
+        flat4 = base3 * (rank + 1)
+        m3._flat_grad = flat4
+        before = gs.started_early
+        m3._grad_ready_hook(m3, flat4)
+        off = 0
+        for p_, sz in zip(m3.parameters(), sizes):
+            p_.grad += flat4[off:off + sz].view_as(p_)
+            off += sz
+        gs.sync()
+        got = torch.cat([p_.grad.reshape(-1) for p_ in m3.parameters()])
+        ok_overlap = ok_overlap and gs.started_early == before and torch.allclose(got, base3 * want + 10.0 * want)
+        # two backwards before one sync(): the first buffer is all-reduced early, the second backward accumulates on top of it
+        for p_ in m3.parameters():
+            p_.grad = None
+        flat5 = base3 * (rank + 1)
+        m3._flat_grad = flat5
+        m3._grad_ready_hook(m3, flat5)
+        adopt(m3, flat5)
+        flat6 = base3 * (rank + 1) * 2.0
+        m3._flat_grad = flat6
+        m3._grad_ready_hook(m3, flat6)                      # waits for + finishes the first collective, issues nothing
+        off = 0
+        for p_, sz in zip(m3.parameters(), sizes):
+            p_.grad += flat6[off:off + sz].view_as(p_)
+            off += sz
+        gs.sync()
+        got = torch.cat([p_.grad.reshape(-1) for p_ in m3.parameters()])
+        ok_overlap = ok_overlap and torch.allclose(got, base3 * want * 3.0)
+        # autograd COPIED the announced views instead of adopting them: refused, never silently un-averaged
+        for p_ in m3.parameters():
+            p_.grad = None
+        flat7 = base3 * (rank + 1)
+        m3._flat_grad = flat7
+        m3._grad_ready_hook(m3, flat7)
+        adopt(m3, flat7.clone())
+        try:
+            gs.sync()
+            ok_overlap = False
+        except RuntimeError:
+            pass
 
         # --- the N>1 training step's host logic (system.GraphedTrainStep): eager warm-up steps, capture of
         # [forward+backward] and [optimizer] as two graphs with the collective issued eagerly in between, replays,
