@@ -31,9 +31,12 @@ FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no pa
 FLOP_PER_POINT_DX = 1115392        # backward chain: 557,696 MAC (no dX into the encodings)
 FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks (the fp8 dW GEMM
-                                                                    # of bf16_f8 is priced against the bf16 peak as well)
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks of the forward / dX chain
+PEAK_TFLOPS_FP8 = 5000.0           # ... and of the MX-scaled fp8 MFMA the dW GEMM of bf16_f8 runs on
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+FLOP_PER_RAY_EVAL = 64 * 982528 + 192 * 1186816      # test_time render: sigma-only coarse pass + full fine pass (290.7 M)
+# `dtype` of the JSON line = the NARROWEST arithmetic inside the timed region
+DTYPE_LABEL = {"bf16_f8": "bf16+fp8(dW)", "bf16": "bf16", "fp32": "f32"}
 
 
 def parse():
@@ -53,7 +56,41 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue the training step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fixed-batch", action="store_true", help="replay one resident batch instead of drawing a fresh one per step")
+    ap.add_argument("--no-extras", action="store_true", help="train mode: skip the eval / render / bf16-storage side measurements")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1: initialise the RCCL process group and route gradients through GradSync anyway (A/B of the N>1 step)")
+    ap.add_argument("--sync-in-graph", type=int, default=None, choices=[0, 1],
+                    help="N>1 graphed step: 1 = ONE graph with the grad-ready-hook all-reduces inside (overlapped), 0 = two graphs "
+                         "with the collectives issued eagerly in between (default: GraphedTrainStep's)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec under torch.distributed.run, one rank per GPU, and pass
+    its exit status on.  A world that does not match --gpus never prints a line."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != a.gpus:
+            print("[bench] WORLD_SIZE=%s but --gpus %d: refusing to report a line for a different world size" % (env_world, a.gpus),
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
+        return
+    if a.gpus <= 1:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        print("[bench] --gpus %d but only %d GPU(s) visible: not running (no silent n_gpus=1 line)" % (a.gpus, n_dev),
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
 
 
 # ---- seeded synthetic inputs (BASELINE.json: no dataset / checkpoint offline).  Self-contained on purpose: the only
@@ -160,6 +197,25 @@ def synth_store(seed, dev, n_img=20, hw=200):
     return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.3, 2.0, 6.0)
 
 
+def load_traffic_db(note):
+    """PMC traffic per launch (profiles/pmc_traffic.json, written by tools/pmc_kernels.sh).  The file is stamped with the
+    digest of the kernel sources it was measured on; a stamp that does not match the sources of THIS build means stale
+    counters: they are then not reported (traffic = null) instead of being passed off as this build's."""
+    if not os.path.exists(TRAFFIC_JSON):
+        note["traffic_note"] = "no profiles/pmc_traffic.json"
+        return {}
+    with open(TRAFFIC_JSON) as fh:
+        db = json.load(fh)
+    from nerf_pl_amd.build import source_digest
+    have, want = db.get("_meta", {}).get("source_digest"), source_digest()
+    if have != want:
+        note["traffic_note"] = "pmc_traffic.json was measured on other kernel sources (digest %s, this build %s): traffic withheld" % (
+            str(have)[:12], want[:12])
+        return {}
+    note["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernel sources (digest %s)" % want[:12]
+    return db
+
+
 def event_time(fn, reps, warm=3, graph=False):
     """Average / min microseconds per call of `fn` by HIP events on torch's current stream (where libnerfhip launches).
     graph=True: `reps` calls are captured into one hipGraph and the replay is timed — for kernels of a few tens of
@@ -230,11 +286,13 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
         for name, fn, flops, nbytes, what in rows:
             avg, mn = event_time(fn, 12, graph=True)
             tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
-            fm, fh = tf / PEAK_TFLOPS[dtype], gbs / PEAK_HBM_GBS
+            # the dW GEMM of bf16_f8 runs on the MX-scaled fp8 MFMA: priced against ITS dense peak
+            peak = PEAK_TFLOPS_FP8 if (dtype == "bf16_f8" and name == "mlp_bwd_dw_kernel") else PEAK_TFLOPS[dtype]
+            fm, fh = tf / peak, gbs / PEAK_HBM_GBS
             key = "%s|%s|%d" % (name, dtype, P)
             out.append({"kernel": "%s<%s> %s pass, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
                         "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
-                        "tflops": round(tf, 1), "gbs": round(gbs, 1), "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                        "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_peak_tflops": peak, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
                         "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
         del acts, raw, g_out, ws
     return out
@@ -242,6 +300,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
 
 def main():
     a = parse()
+    self_launch(a)
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block on the
     # first communicator) are diverted to stderr for the whole run; the result goes to the saved descriptor.
     sys.stdout.flush()
@@ -251,13 +310,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    rccl_nranks = None
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         if dist.get_world_size() != a.gpus:
-            print("[bench] WORLD_SIZE %d != --gpus %d" % (dist.get_world_size(), a.gpus), file=sys.stderr, flush=True)
+            print("[bench] RCCL world size %d != --gpus %d" % (dist.get_world_size(), a.gpus), file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(2)
+        # what RCCL itself thinks the communicator is: every rank contributes a 1 to a sum all-reduce
+        one = torch.ones(1, device=torch.device("cuda", local))
+        dist.all_reduce(one)
+        rccl_nranks = int(one.item())
+        if rccl_nranks != a.gpus:
+            print("[bench] RCCL all-reduce saw %d ranks, --gpus %d" % (rccl_nranks, a.gpus), file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -285,7 +359,7 @@ def main():
 
     system, opt = build_system(a.dtype)
     models, emb = system.models, system.embeddings
-    grad_sync = GradSync(models) if world > 1 else None
+    grad_sync = GradSync(models, force=a.force_dist) if dist is not None else None
     rays = synth_rays(1234 + rank, B).to(dev)                 # fixed batch: render mode, per-kernel timings
     store = synth_store(4321 + rank, dev)                     # each rank owns its own images and draws its own batches
     gen = torch.Generator(device=dev)
@@ -308,7 +382,8 @@ def main():
         # fresh batches are drawn INSIDE the graph (RayStore.sample with the default generator: randint + gen_rays + gather are
         # captured, torch's graph-safe Philox state advances per replay): no per-step copies into static buffers
         in_graph = not a.fixed_batch
-        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=(lambda: store.sample(B)) if in_graph else None)
+        kw = {} if a.sync_in_graph is None else {"sync_in_graph": bool(a.sync_in_graph)}
+        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=(lambda: store.sample(B)) if in_graph else None, **kw)
               if not a.no_graph else None}
 
         def eager(batch):
@@ -380,10 +455,7 @@ def main():
 
     if rank == 0:
         extra = {}
-        traffic_db = {}
-        if os.path.exists(TRAFFIC_JSON):
-            with open(TRAFFIC_JSON) as fh:
-                traffic_db = json.load(fh)
+        traffic_db = load_traffic_db(extra)
         if a.mode == "train":                                  # forward-only rate of the same workload
             for _ in range(5):
                 render_step()
@@ -392,7 +464,29 @@ def main():
             for _ in range(30):
                 render_step()
             torch.cuda.synchronize()
-            extra["render_fwd_rays_per_s_per_gpu"] = round(B * 30 / (time.perf_counter() - t1), 1)
+            t_render = (time.perf_counter() - t1) / 30
+            extra["render_fwd_rays_per_s_per_gpu"] = round(B / t_render, 1)
+            # train-mode forward = full coarse + full fine network: FLOP_PER_POINT_FULL x (2S + N) points per ray
+            extra["render_fwd_frac_mfma"] = round(FLOP_PER_POINT_FULL * B * (2 * S + N) / t_render / 1e12 / PEAK_TFLOPS[a.dtype], 4)
+            if world == 1 and not a.no_extras:
+                # BASELINE configs[4] inside the default run: full 800x800 images through eval.py's batched_inference contract
+                # (test_time, 32768-ray hipGraph chunks, pixels streamed to pinned host memory: D2H inside the timed region)
+                from nerf_pl_amd.inference import GraphRenderer
+                e_rays = synth_rays(77, a.image_rays).to(dev)
+                gr = GraphRenderer(models, emb, S, N, False, True)
+                gr.render_to_host(e_rays, keys=("rgb_fine", "depth_fine"))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    gr.render_to_host(e_rays, keys=("rgb_fine", "depth_fine"))
+                torch.cuda.synchronize()
+                t_img = (time.perf_counter() - t1) / 3
+                extra["eval_ms_per_image"] = round(t_img * 1e3, 2)
+                extra["eval_rays_per_s"] = round(a.image_rays / t_img, 1)
+                extra["eval_frac_mfma"] = round(FLOP_PER_RAY_EVAL * a.image_rays / t_img / 1e12 / PEAK_TFLOPS[a.dtype], 4)
+                extra["eval_note"] = ("configs[4]: %d-ray image, 32768-ray hipGraph chunks x (%d+%d) samples, test_time (sigma-only coarse "
+                                      "pass), D2H of rgb+depth included; 3 images after 1 warm-up" % (a.image_rays, S, N))
+                del gr, e_rays
 
         # ---- the north-star kernel: fine-pass fused MLP forward, inference variant (B x (S+N) points) ----
         with torch.no_grad():
@@ -430,7 +524,7 @@ def main():
             # whole-step MFMA fraction: algorithmic FLOPs of the step (GEMMs only) over the step time
             step_flops = (FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW) * B * (2 * S + N)
             extra["step_frac_mfma"] = round(step_flops / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
-            if a.dtype == "bf16_f8" and world == 1:
+            if a.dtype == "bf16_f8" and world == 1 and not a.no_extras:
                 # the same step with bf16 storage of the saved tensors (no fp8 anywhere), for reference
                 sys2, opt2 = build_system("bf16")
                 step2, _ = make_stepper(sys2, opt2, None)
@@ -441,7 +535,7 @@ def main():
             extra["roofline"] = ns
 
         total_rays = (a.image_rays if a.mode == "eval" else world * B) * a.steps
-        arith = {"bf16_f8": "bf16", "bf16": "bf16", "fp32": "f32"}[a.dtype]
+        arith = DTYPE_LABEL[a.dtype]
         mlp_note = {"bf16_f8": "bf16 MFMA MLP (forward + dX chain), dW GEMM on block-scaled e4m3 copies of the saved tensors",
                     "bf16": "bf16 MFMA MLP", "fp32": "exact-fp32 MFMA MLP"}[a.dtype]
         out = {
@@ -467,7 +561,13 @@ def main():
                        "issue": ("hipGraph replay of the whole step" if (a.mode == "train" and state["graphed"] is not None
                                                                          and state["graphed"].graph is not None)
                                  else "hipGraph replay per 32768-ray chunk" if a.mode == "eval" else "eager"),
-                       "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if world > 1 and a.mode == "train" else "")},
+                       "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if dist is not None and a.mode == "train" else ""),
+                       "rccl_nranks": rccl_nranks,
+                       "grad_sync": (None if (grad_sync is None or a.mode != "train") else
+                                     ("one hipGraph, all-reduces issued from the grad-ready hooks inside it"
+                                      if (state["graphed"] is not None and not state["graphed"]._two_graphs()) else
+                                      "two hipGraphs (fwd+bwd | Adam), flat-buffer all-reduces issued eagerly in between"
+                                      if state["graphed"] is not None else "eager, hook-overlapped all-reduces"))},
         }
         out.update(extra)
         if not a.no_cpu_baseline and world == 1:                # reported baseline: rank 0 at N=1 only

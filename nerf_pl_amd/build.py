@@ -86,6 +86,20 @@ def _digest(src, flags):
     return h.hexdigest()
 
 
+def source_digest():
+    """One digest of everything the kernels are built from (csrc/*, the C header, the flags): measurements taken on one build
+    (profiles/pmc_traffic.json) are stamped with it, and bench.py refuses counters stamped with another."""
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(ROOT, "include", "nerfhip.h"))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS + [V3_SCHED]).encode())
+    return h.hexdigest()
+
+
 def _compile(job):
     src, obj, flags = job
     cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]

@@ -73,7 +73,9 @@ class RayStore:
     (blender.py:81-84); `image_rays(i)` the (H*W, 8) rays of one image (validation / eval)."""
 
     def __init__(self, poses, rgbs, H, W, focal, near, far, use_ndc=False, ndc_near_plane=1.0):
-        with torch.cuda.device(poses.device if poses.is_cuda else torch.cuda.current_device()):
+        if not poses.is_cuda:
+            require_gpu(poses)                          # raises: no CPU fallback
+        with torch.cuda.device(poses.device):
             require_gpu(poses, rgbs)
         self.poses = poses.contiguous()
         self.rgbs = rgbs.reshape(-1, 3).contiguous()

@@ -26,8 +26,9 @@ B, S, N = 1024, 64, 64
 STEPS = 1200
 LR_AT = {1: 5e-4, 600: 2.5e-4, 900: 1.25e-4}        # steplr, decay_gamma 0.5 (README.md:75-83), compressed
 EVAL_AT = (1000, 1050, 1100, 1150, 1200)
-N_LIVE, MAX_SEEDS = 12, 24
-DEAD_BELOW_DB = 15.0                                # fp32 PSNR under this at the end = the all-white dead init
+N_LIVE, MAX_SEEDS = 16, 40
+DEAD_BELOW_DB = 12.0                                # fp32 PSNR under this = the all-white dead init (7.3 dB on this scene)
+DEAD_CHECK_AT = 150                                 # ... checked once, early in the fp32 run
 N_TRAIN_RAYS, N_VAL_RAYS = 400000, 16384
 
 
@@ -37,8 +38,9 @@ def make_data(dev, **scene):
     return rays, rgbs, rays_val, rgb_val
 
 
-def train_curve(dtype, dev, data, init, jitter_seed, steps=STEPS, lr_at=LR_AT, eval_at=EVAL_AT):
-    """One training run of `steps` 1024-ray steps; returns {step: PSNR on the held-out rays}."""
+def train_curve(dtype, dev, data, init, jitter_seed, steps=STEPS, lr_at=LR_AT, eval_at=EVAL_AT, dead_check=None):
+    """One training run of `steps` 1024-ray steps; returns {step: PSNR on the held-out rays}, or None when `dead_check` =
+    (step, dB) finds the run still under `dB` at `step`."""
     from nerf_pl_amd.inference import batched_inference
     from nerf_pl_amd.system import NeRFSystem
     rays, rgbs, rays_val, rgb_val = data
@@ -64,10 +66,14 @@ def train_curve(dtype, dev, data, init, jitter_seed, steps=STEPS, lr_at=LR_AT, e
         opt.zero_grad(set_to_none=True)
         out["loss"].backward()
         opt.step()
-        if step in eval_at:
+        if step in eval_at or (dead_check is not None and step == dead_check[0]):
             with torch.no_grad():
                 img = batched_inference(system.models, system.embeddings, rays_val, S, N, False, 32768, True)["rgb_fine"]
-            curve[step] = (-10 * torch.log10(torch.mean((img - rgb_val) ** 2))).item()
+            psnr = (-10 * torch.log10(torch.mean((img - rgb_val) ** 2))).item()
+            if step in eval_at:
+                curve[step] = psnr
+            if dead_check is not None and step == dead_check[0] and psnr < dead_check[1]:
+                return None
     return curve
 
 
@@ -83,12 +89,12 @@ def paired_statistics(dev, dtypes=("bf16", "bf16_f8"), n_live=N_LIVE, max_seeds=
             break
         torch.manual_seed(seed)
         init = [NeRF().state_dict(), NeRF().state_dict()]    # default nn.Linear init, coarse then fine (train.py:38-42)
-        c32 = train_curve("fp32", dev, data, init, 1000 + seed, **train_kw)
-        f32 = sum(c32[s] for s in eval_at) / len(eval_at)
-        if f32 < DEAD_BELOW_DB:
+        c32 = train_curve("fp32", dev, data, init, 1000 + seed, dead_check=(DEAD_CHECK_AT, DEAD_BELOW_DB), **train_kw)
+        if c32 is None:
             dead.append(seed)
-            log("seed %d: dead init (fp32 %.2f dB), replaced" % (seed, f32))
+            log("seed %d: dead init (fp32 under %.0f dB at step %d), replaced" % (seed, DEAD_BELOW_DB, DEAD_CHECK_AT))
             continue
+        f32 = sum(c32[s] for s in eval_at) / len(eval_at)
         row = {"seed": seed, "fp32": c32}
         finals["fp32"].append(f32)
         for dt in dtypes:

@@ -46,6 +46,10 @@ for d in dtypes:
                 "FETCH_SIZE_KB": round(cs["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(cs["WRITE_SIZE"], 1),
                 "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024), "kernel": name,
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/kbench.py --dtype %s --samples %d" % (d, S)}
-json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerf_pl_amd.build import source_digest  # noqa: E402
+out = dict(res)
+out["_meta"] = {"source_digest": source_digest(), "note": "digest of nerf_pl_amd/csrc + include/nerfhip.h + build flags the counters were taken on"}
+json.dump(out, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 for k, v in sorted(res.items()):
     print(k.ljust(44), "fetch %9.1f KB x2  write %9.1f KB  => %7.1f MB" % (v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"], v["hbm_bytes_per_launch"] / 1e6))

@@ -31,6 +31,7 @@ def parse_scene(s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", default=None)
+    ap.add_argument("--sweep-list", default=None)
     ap.add_argument("--gate", action="store_true")
     ap.add_argument("--scene", default="")
     ap.add_argument("--auto", type=float, default=None, help="with --sweep --gate: gate on the swept scene whose fp32 PSNR is closest to this")
@@ -42,22 +43,25 @@ def main():
     from nerf_pl_amd.models import NeRF
     report = {}
     scene = {k: v[0] for k, v in parse_scene(a.scene).items()}
-    if a.sweep:
+    if a.sweep or a.sweep_list:
         grid = parse_scene(a.sweep)
         keys = sorted(grid)
         rows = []
-        for combo in itertools.product(*[grid[k] for k in keys]):
-            sc = dict(zip(keys, combo))
+        combos = [dict(zip(keys, c)) for c in itertools.product(*[grid[k] for k in keys])]
+        if a.sweep_list:                       # explicit scenes instead of a grid: "freq=6 amp=0.2; freq=10 amp=0.3"
+            combos = [{k: v[0] for k, v in parse_scene(t).items()} for t in a.sweep_list.split(";")]
+        for sc in combos:
             data = G.make_data(dev, **sc)
             vals = []
             for seed in (0, 1, 3):
                 torch.manual_seed(seed)
                 init = [NeRF().state_dict(), NeRF().state_dict()]
                 t0 = time.time()
-                c = G.train_curve("fp32", dev, data, init, 1000 + seed)
+                c = G.train_curve("fp32", dev, data, init, 1000 + seed, dead_check=(G.DEAD_CHECK_AT, G.DEAD_BELOW_DB))
+                if c is None:
+                    continue
                 f = sum(c[s] for s in G.EVAL_AT) / len(G.EVAL_AT)
-                if f >= G.DEAD_BELOW_DB:
-                    vals.append(f)
+                vals.append(f)
                 print("sweep", sc, "seed", seed, "fp32 %.3f dB" % f, {k: round(v, 2) for k, v in c.items()}, "%.1f s" % (time.time() - t0), flush=True)
                 if len(vals) == 2:
                     break
