@@ -110,6 +110,14 @@ int nerfhip_composite_bwd(const float* raw, int raw_ch, const float* z, const fl
                           const float* g_depth, const float* g_opacity, const float* g_weights,
                           float* g_raw, int64_t B, int S, nerfhip_stream_t stream);
 
+/* Training fast path (train.py:103-117 with losses.py:9-14): composite_fwd (raw_ch 4) + d MSE / d rgb of every ray against
+ * `target` (B,3), i.e. g_rgb = (rgb - target) * grad_scale with grad_scale = 2 / (3 B) for one image's mean-squared error, +
+ * composite_bwd for that g_rgb, in ONE launch.  Writes weights (B,S; NULL ok), rgb (B,3), depth (B), opacity (B) and
+ * g_raw (B,S,4) = d loss / d raw — bit-identical to composite_fwd -> mse_psnr -> composite_bwd.                          */
+int nerfhip_composite_train(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                            int white_back, const float* target, float grad_scale, float* weights, float* rgb, float* depth,
+                            float* opacity, float* g_raw, int64_t B, int S, nerfhip_stream_t stream);
+
 /* ---- a3/a4. NeRF MLP  (models/nerf.py:42-124; D=8 W=256 skips=[4] in 63/27) -------------
  * Parameters are repacked once per weight update into the MFMA A-fragment stream the
  * kernel consumes (layout: DESIGN.md §3).  weights_host[i]/biases_host[i] are HOST arrays of
@@ -155,6 +163,11 @@ int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_
  * of a model whose weights do not change between its forward and its backward                                   */
 int nerfhip_mlp_pack_weights_train(const float* const* weights_host, const float* const* biases_host, void* packed,
                                    void* packed_bwd, int dtype, nerfhip_stream_t stream);
+/* ... of `n_models` (<= 4) models in ONE launch: weights_host / biases_host hold n_models x 12 DEVICE pointers (model-major),
+ * packed_host / packed_bwd_host one DEVICE buffer per model.  A training step packs its coarse and its fine network here. */
+int nerfhip_mlp_pack_weights_train_multi(const float* const* weights_host, const float* const* biases_host,
+                                         void* const* packed_host, void* const* packed_bwd_host, int n_models, int dtype,
+                                         nerfhip_stream_t stream);
 size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype);
 int nerfhip_mlp_dw_splits(int64_t n_points, int dtype);   /* total (job, point-split) workgroups = partial slabs */
 size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype);
@@ -208,6 +221,12 @@ int nerfhip_ndc_rays(int H, int W, double focal, float near, const float* rays_o
 int nerfhip_gen_rays(const float* c2w, const int64_t* pixel_ids, int64_t first_pixel, int64_t n, int H, int W,
                      double focal, float near, float far, int use_ndc, float ndc_near_plane, float* rays,
                      nerfhip_stream_t stream);
+/* A training batch in one launch (the reference's Dataset.__getitem__ + DataLoader collate, blender.py:81-84 /
+ * train.py:89-94): rays as nerfhip_gen_rays for the n pixel ids, and rgbs (n,3) = rgbs_all[pixel_ids] gathered from the
+ * device-resident pixel colours rgbs_all (n_images*H*W, 3).                                                      */
+int nerfhip_sample_batch(const float* c2w, const int64_t* pixel_ids, const float* rgbs_all, int64_t n, int H, int W,
+                         double focal, float near, float far, int use_ndc, float ndc_near_plane, float* rays, float* rgbs,
+                         nerfhip_stream_t stream);
 
 #ifdef __cplusplus
 }

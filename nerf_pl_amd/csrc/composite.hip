@@ -200,7 +200,126 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     }
 }
 
+// Training fast path ("fused loss + PSNR + composite backward seed"): the quadrature of composite_fwd_kernel<4>,
+// the MSE residual of the ray against its target colour (losses.py:9-14: d loss / d rgb = 2 (rgb - t) / n, `gscale` = 2 / n) and
+// the backward of composite_bwd_kernel<4> for exactly that upstream gradient, in ONE launch — three launches (forward, loss
+// gradient scaling, backward) and an HBM round trip of rgb fewer per pass.  Every value is formed by the same expressions in
+// the same order as in the separate kernels, so g_raw is bit-identical to composite_fwd -> mse_psnr -> composite_bwd.
+__global__ __launch_bounds__(256) void composite_train_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                              const float* __restrict__ rays, const float* __restrict__ noise,
+                                                              float noise_std, int white_back, const float* __restrict__ target,
+                                                              float gscale, float* __restrict__ weights, float* __restrict__ rgb,
+                                                              float* __restrict__ depth, float* __restrict__ opacity,
+                                                              float* __restrict__ g_raw, int64_t B, int S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    float* T_s = lds + (size_t)wave * S;       // transmittance T_i
+    const float dnorm = ray_dnorm(rays, r);
+    const float* zr = z + r * S;
+    // ---- forward sweep (composite_fwd_kernel<4>) ----
+    double carry = 1.0;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_o = 0.f;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < S;
+        float sigma = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, zi = 0.f, zn = 0.f, nz = 0.f;
+        if (valid) {
+            zi = zr[i];
+            zn = (i + 1 < S) ? zr[i + 1] : zi;
+            const float4 v = reinterpret_cast<const float4*>(raw)[r * S + i];
+            cr = v.x; cg = v.y; cb = v.z; sigma = v.w;
+            if (noise) nz = nh_mul(noise[r * S + i], noise_std);
+        }
+        const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
+        const double f = valid ? (double)t.sh : 1.0;
+        const double incl = wave_incl_prod(f, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(excl * carry);
+        carry = carry * __shfl(incl, 63, 64);
+        const float w = valid ? nh_mul(t.alpha, T) : 0.0f;
+        if (valid) {
+            if (weights) weights[r * S + i] = w;
+            T_s[i] = T;
+        }
+        acc_o += w;
+        acc_r += w * cr; acc_g += w * cg; acc_b += w * cb;
+        acc_d += w * zi;
+    }
+    acc_o = wave_sum(acc_o);
+    acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b); acc_d = wave_sum(acc_d);
+    const float bg = white_back ? nh_sub(1.0f, acc_o) : 0.0f;
+    const float out_r = acc_r + bg, out_g = acc_g + bg, out_b = acc_b + bg;
+    if (lane == 0) {
+        opacity[r] = acc_o;
+        rgb[r * 3 + 0] = out_r;
+        rgb[r * 3 + 1] = out_g;
+        rgb[r * 3 + 2] = out_b;
+        depth[r] = acc_d;
+    }
+    // ---- d loss / d rgb of this ray (mse_psnr_kernel: (rgb - t) * (2 / n)) ----
+    const float gr = nh_mul(nh_sub(out_r, target[r * 3]), gscale);
+    const float gg = nh_mul(nh_sub(out_g, target[r * 3 + 1]), gscale);
+    const float gb = nh_mul(nh_sub(out_b, target[r * 3 + 2]), gscale);
+    const float gd = 0.f;
+    float gconst = 0.f;
+    if (white_back) gconst -= (gr + gg + gb);
+    __builtin_amdgcn_wave_barrier();
+    // ---- reverse sweep (composite_bwd_kernel<4>): exclusive suffix sum of gw_k*w_k, colour and density gradients ----
+    float tail = 0.f;
+    const int nchunk = (S + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int i = c * 64 + lane;
+        const bool valid = i < S;
+        SampleTerms t{};
+        float T = 0.f, gw = 0.f;
+        if (valid) {
+            const float zi = zr[i];
+            const float zn = (i + 1 < S) ? zr[i + 1] : zi;
+            const float4 v = reinterpret_cast<const float4*>(raw)[r * S + i];
+            const float nz = noise ? nh_mul(noise[r * S + i], noise_std) : 0.f;
+            t = sample_terms(zi, zn, i == S - 1, dnorm, v.w, nz);
+            T = T_s[i];
+            const float w = t.alpha * T;
+            gw = gconst + 0.f;
+            gw += gr * v.x + gg * v.y + gb * v.z + gd * zi;
+            float* o = g_raw + (r * S + i) * 4;
+            o[0] = w * gr; o[1] = w * gg; o[2] = w * gb;
+        }
+        const float vv = valid ? gw * (t.alpha * T) : 0.f;
+        float incl = vv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float tt = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += tt;
+        }
+        const float suf = (incl - vv) + tail;
+        tail += __shfl(incl, 0, 64);
+        if (valid) {
+            const float g_alpha = gw * T - suf / t.sh;
+            const float g_sigma = t.on ? g_alpha * t.delta * t.e : 0.f;
+            g_raw[(r * S + i) * 4 + 3] = g_sigma;
+        }
+    }
+}
+
 }  // namespace nerfhip
+
+extern "C" int nerfhip_composite_train(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                                       int white_back, const float* target, float grad_scale, float* weights, float* rgb,
+                                       float* depth, float* opacity, float* g_raw, int64_t B, int S, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 1 && S <= 2048);
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(raw && z && rays && target && rgb && depth && opacity && g_raw);
+    if ((((uintptr_t)raw) | ((uintptr_t)g_raw)) & 15) return NERFHIP_E_ALIGN;
+    if (noise_std == 0.0f) noise = nullptr;
+    hipLaunchKernelGGL(nerfhip::composite_train_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)4 * S * sizeof(float),
+                       (hipStream_t)stream, raw, z, rays, noise, noise_std, white_back, target, grad_scale, weights, rgb, depth,
+                       opacity, g_raw, B, S);
+    return nerfhip_launch_status();
+}
 
 extern "C" int nerfhip_composite_fwd(const float* raw, int raw_ch, const float* z, const float* rays,
                                      const float* noise, float noise_std, int white_back, float* weights, float* rgb,

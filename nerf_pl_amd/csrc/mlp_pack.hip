@@ -29,6 +29,24 @@ __global__ __launch_bounds__(64) void mlp_pack_train_kernel(ParamTable P, uint8_
             pack_bwd_piece<PREC>(P, g - nf, threadIdx.x);
 }
 
+// the same for up to kPackMaxModels models in ONE launch (blockIdx.y = model): a training step's coarse and fine network
+constexpr int kPackMaxModels = 4;
+struct MultiPackTable {
+    ParamTable P[kPackMaxModels];
+    uint8_t* packed[kPackMaxModels];
+    uint8_t* packed_bwd[kPackMaxModels];
+};
+template <int PREC>
+__global__ __launch_bounds__(64) void mlp_pack_train_multi_kernel(MultiPackTable T) {
+    const int nf = mlp::padded_pieces(PREC);
+    const int g = blockIdx.x, m = blockIdx.y;
+    if (g < nf)
+        reinterpret_cast<uint4*>(T.packed[m] + (size_t)g * mlp::kPieceBytes)[threadIdx.x] = pack_fwd_piece<PREC>(T.P[m], g, threadIdx.x);
+    else
+        reinterpret_cast<uint4*>(T.packed_bwd[m] + (size_t)(g - nf) * mlp::kPieceBytes)[threadIdx.x] =
+            pack_bwd_piece<PREC>(T.P[m], g - nf, threadIdx.x);
+}
+
 static int pack_prec(int dtype) {       // NERFHIP_BF16_F8 shares the bf16 weight images: only the saved tensors differ
     if (dtype == NERFHIP_BF16_F8) return NERFHIP_BF16;
     return (dtype == NERFHIP_F32 || dtype == NERFHIP_BF16) ? dtype : -1;
@@ -108,5 +126,33 @@ extern "C" int nerfhip_mlp_pack_weights_train(const float* const* weights_host, 
     else
         hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed, (uint8_t*)packed_bwd);
+    return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_mlp_pack_weights_train_multi(const float* const* weights_host, const float* const* biases_host,
+                                                    void* const* packed_host, void* const* packed_bwd_host, int n_models, int dtype,
+                                                    nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(weights_host && biases_host && packed_host && packed_bwd_host);
+    NERFHIP_CHECK_ARG(n_models >= 1 && n_models <= nerfhip::kPackMaxModels);
+    dtype = nerfhip::pack_prec(dtype);
+    if (dtype < 0) return NERFHIP_E_UNSUPPORTED;
+    nerfhip::MultiPackTable T;
+    for (int m = 0; m < nerfhip::kPackMaxModels; ++m) {
+        const int mm = m < n_models ? m : 0;
+        NERFHIP_CHECK_ARG(packed_host[mm] && packed_bwd_host[mm]);
+        if ((((uintptr_t)packed_host[mm]) | ((uintptr_t)packed_bwd_host[mm])) & 15) return NERFHIP_E_ALIGN;
+        T.packed[m] = (uint8_t*)packed_host[mm];
+        T.packed_bwd[m] = (uint8_t*)packed_bwd_host[mm];
+        for (int i = 0; i < 12; ++i) {
+            NERFHIP_CHECK_ARG(weights_host[12 * mm + i] && biases_host[12 * mm + i]);
+            T.P[m].w[i] = weights_host[12 * mm + i];
+            T.P[m].b[i] = biases_host[12 * mm + i];
+        }
+    }
+    const dim3 grid((unsigned)(nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_padded_pieces(dtype)), (unsigned)n_models);
+    if (dtype == NERFHIP_BF16)
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_BF16>, grid, dim3(64), 0, (hipStream_t)stream, T);
+    else
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_F32>, grid, dim3(64), 0, (hipStream_t)stream, T);
     return nerfhip_launch_status();
 }

@@ -79,13 +79,20 @@ __global__ __launch_bounds__(256) void ndc_rays_kernel(float sx, float sy, float
 }
 
 // pix: global pixel ids (image * H*W + row * W + col) or NULL = ids first_pix .. first_pix + n - 1
+// rgbs_all / rgbs_out (both or neither): the batch's target colours rgbs_all[id] gathered in the same launch (blender.py:81-84)
 __global__ __launch_bounds__(256) void gen_rays_kernel(const float* __restrict__ c2w_all, const int64_t* __restrict__ pix,
                                                         int64_t first_pix, int64_t n, int H, int W, float focal, float near,
                                                         float far, int use_ndc, float ndc_plane, float sx, float sy,
-                                                        float* __restrict__ rays) {
+                                                        float* __restrict__ rays, const float* __restrict__ rgbs_all,
+                                                        float* __restrict__ rgbs_out) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const int64_t id = pix ? pix[r] : first_pix + r;
+    if (rgbs_out) {
+        rgbs_out[3 * r] = rgbs_all[3 * id];
+        rgbs_out[3 * r + 1] = rgbs_all[3 * id + 1];
+        rgbs_out[3 * r + 2] = rgbs_all[3 * id + 2];
+    }
     const int64_t hw = (int64_t)H * W;
     const int64_t img = id / hw, q = id - img * hw;
     float d[3], o[3], w[3];
@@ -140,6 +147,19 @@ extern "C" int nerfhip_gen_rays(const float* c2w, const int64_t* pixel_ids, int6
     if (((uintptr_t)rays) & 15) return NERFHIP_E_ALIGN;
     hipLaunchKernelGGL(nerfhip::gen_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c2w,
                        pixel_ids, first_pixel, n, H, W, (float)focal, near, far, use_ndc, ndc_near_plane, ndc_scale(W, focal),
-                       ndc_scale(H, focal), rays);
+                       ndc_scale(H, focal), rays, (const float*)nullptr, (float*)nullptr);
+    return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_sample_batch(const float* c2w, const int64_t* pixel_ids, const float* rgbs_all, int64_t n, int H, int W,
+                                    double focal, float near, float far, int use_ndc, float ndc_near_plane, float* rays,
+                                    float* rgbs, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(n >= 0 && H > 0 && W > 0);
+    if (n == 0) return 0;
+    NERFHIP_CHECK_ARG(c2w && pixel_ids && rgbs_all && rays && rgbs);
+    if (((uintptr_t)rays) & 15) return NERFHIP_E_ALIGN;
+    hipLaunchKernelGGL(nerfhip::gen_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c2w,
+                       pixel_ids, (int64_t)0, n, H, W, (float)focal, near, far, use_ndc, ndc_near_plane, ndc_scale(W, focal),
+                       ndc_scale(H, focal), rays, rgbs_all, rgbs);
     return nerfhip_launch_status();
 }
