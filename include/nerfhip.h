@@ -182,6 +182,31 @@ int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, cons
                            void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
                            int accumulate, int dtype, int phases, nerfhip_stream_t stream);
 
+/* The backward of SEVERAL models (<= 2: a training step's fine and coarse network) with ONE weight-gradient launch and ONE
+ * reduce launch for all of them: per model its chain kernel, then one dW GEMM whose workgroups are shared out over the 12 jobs
+ * of every model in proportion to the models' points (equal ring iterations per workgroup), then one reduce.  All `_host`
+ * arguments are HOST arrays with one entry per model (grad_w_host / grad_b_host: n_models x 12 DEVICE pointers, model-major);
+ * dw_workspace holds nerfhip_mlp_dw_workspace_bytes_multi() bytes.  `adam` (NULL ok; requires accumulate == 0): apply the Adam
+ * update of nerfhip_adam_step to every model's flat parameter buffer inside the reduce kernel — each model's parameters,
+ * exp_avg, exp_avg_sq are flat fp32 buffers laid out like its flat gradient buffer grad_flat (the 24 gradient tensors
+ * contiguous: w0..w11, b0..b11) — for single-GPU steps, where no all-reduce sits between gradients and update.
+ * g_scale (NULL = 1): a DEVICE scalar every g_out is multiplied by inside the chain kernels — the upstream d L / d loss of an
+ * autograd backward, applied without a scaling launch.                                                                   */
+typedef struct nerfhip_adam_fused {
+    int n_models;
+    float* param[2];
+    float* exp_avg[2];
+    float* exp_avg_sq[2];
+    const float* grad_flat[2];
+    float* state;                 /* {step count, arrival ticket} as for nerfhip_adam_step */
+    float lr, beta1, beta2, eps, weight_decay;
+} nerfhip_adam_fused;
+size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_host, int n_models, int dtype);
+int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const float* const* out_host, const int64_t* n_host,
+                          const void* const* packed_bwd_host, const void* const* acts_host, void* const* dys_host,
+                          void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host, int accumulate, int dtype,
+                          int phases, const float* g_scale, const nerfhip_adam_fused* adam, nerfhip_stream_t stream);
+
 /* d loss / d x of NeRF.forward on pre-embedded inputs (nerf.py:100-124 is differentiable w.r.t. x): from the dY slabs a
  * nerfhip_mlp_bwd call left in `dys`,  gx[:, 0:63] = W_1^T dY_1 + W_5[:, :63]^T dY_5,  gx[:, 63:90] = W_dir[:, 256:]^T dY_dir.
  * w_xyz1 / w_xyz5 / w_dir: the (out,in) fp32 weights of xyz_encoding_1, xyz_encoding_5, dir_encoding; gx (n, >= 90) with

@@ -64,10 +64,29 @@ SIGNATURES = {
                           ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64), _int, _c_void_p, _f32, _f32, _f32, _f32, _f32, _c_void_p],
     "nerfhip_mlp_bwd": [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
+    "nerfhip_sample_batch": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, ctypes.c_double, _f32, _f32, _int, _f32, _c_void_p,
+                             _c_void_p, _c_void_p],
+    "nerfhip_mlp_pack_weights_train_multi": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                             ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
+    "nerfhip_composite_train": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
+                                _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
+    "nerfhip_mlp_dw_workspace_bytes_multi": [ctypes.POINTER(_i64), _int, _int],
+    "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
+                              ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
+                              ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p, _c_void_p, _c_void_p],
 }
+
+
+class AdamFused(ctypes.Structure):
+    """include/nerfhip.h: nerfhip_adam_fused"""
+    _fields_ = [("n_models", _int), ("param", _c_void_p * 2), ("exp_avg", _c_void_p * 2), ("exp_avg_sq", _c_void_p * 2),
+                ("grad_flat", _c_void_p * 2), ("state", _c_void_p), ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32),
+                ("weight_decay", _f32)]
+
 _RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t,
              "nerfhip_mlp_act_bytes": ctypes.c_size_t, "nerfhip_mlp_packed_bwd_bytes": ctypes.c_size_t,
-             "nerfhip_mlp_dy_bytes": ctypes.c_size_t, "nerfhip_mlp_dw_workspace_bytes": ctypes.c_size_t}
+             "nerfhip_mlp_dy_bytes": ctypes.c_size_t, "nerfhip_mlp_dw_workspace_bytes": ctypes.c_size_t,
+             "nerfhip_mlp_dw_workspace_bytes_multi": ctypes.c_size_t}
 
 _lib = None
 

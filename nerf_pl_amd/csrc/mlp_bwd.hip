@@ -18,6 +18,7 @@
 #include "common.h"
 #include "mlp_layout.h"
 #include "f8_store.h"
+#include "adam_math.h"
 
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2  // cache-policy bits of the dY stores: 2 = nt (-7 %; whole training step 1.65 -> 1.51 ms)
@@ -266,8 +267,8 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char*
 
 template <int PREC, bool F8>
 __global__ __launch_bounds__(BwdTraits<PREC>::NW * 64, BwdTraits<PREC>::WPS)
-void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ out, int64_t n,
-                          const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
+void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ g_scale, const float* __restrict__ out,
+                          int64_t n, const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
                           uint8_t* __restrict__ dys_base) {
     static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
     using Slab = typename BwdTraits<PREC>::Slab;
@@ -287,6 +288,10 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     float4 g = reinterpret_cast<const float4*>(g_out)[pc];
     const float4 o = reinterpret_cast<const float4*>(out)[pc];
     if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);               // padded points contribute nothing
+    if (g_scale) {                                                 // upstream d L / d loss as a device scalar (NULL = 1)
+        const float sc = *g_scale;
+        g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+    }
 
     __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(acts_base) + (size_t)tile * kActTile, 0, kActTile, 0x00020000);
@@ -371,10 +376,18 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
 // Jobs + their point-range splits.  A workgroup = (job, split).  Every job gets the SAME number of splits: a
 // workgroup's time is set by its iteration (tile) count, not by its bytes per tile (10-36 KiB) — measured: splits
 // proportional to bytes made the launch 20 % slower (651 vs 544 us at 1024x192) than uniform splits.
+// One launch serves up to kDwMaxModels models (a training step's fine and coarse network): job j belongs to model j / 12 and
+// carries that model's tensors, so ONE dW launch and ONE reduce launch cover the whole step.
+constexpr int kDwMaxModels = 2;
+constexpr int kDwMaxJobs = kDwMaxModels * kNumDwJobs;
 struct DwJobTable {
-    DwJob job[kNumDwJobs];
-    int nsplit[kNumDwJobs];
-    int soff[kNumDwJobs + 1];     // prefix sums: workgroup / partial-slab index of (job j, split 0)
+    DwJob job[kDwMaxJobs];
+    int nsplit[kDwMaxJobs];
+    int soff[kDwMaxJobs + 1];     // prefix sums: workgroup / partial-slab index of (job j, split 0); = total for j >= njobs
+    const uint8_t* acts[kDwMaxJobs];   // saved activations of the job's model
+    const uint8_t* dys[kDwMaxJobs];    // dY slabs of the job's model
+    int64_t ntiles[kDwMaxJobs];        // 32-point wave tiles of the job's model
+    int njobs;
 };
 #ifndef NERFHIP_DW_DEPTH
 #define NERFHIP_DW_DEPTH 4
@@ -399,8 +412,7 @@ template <> struct DwTraits<NERFHIP_F32> {
 
 template <int PREC>
 __global__ __launch_bounds__(512, 2)
-void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restrict__ acts_base,
-                       const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
+void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     constexpr int SPP = DwTraits<PREC>::SPP, DEPTH = DwTraits<PREC>::DEPTH, MAXP = DwTraits<PREC>::MAXP;
     constexpr int LPW = (MAXP + 7) / 8;                       // DMA instructions per wave per stage (padded)
     constexpr int STAGE_BYTES = DwTraits<PREC>::STAGE_BYTES;
@@ -411,9 +423,12 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int jid = 0;
 #pragma unroll
-    for (int j = 1; j < kNumDwJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
+    for (int j = 1; j < kDwMaxJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
     const int nsplit = jobs.nsplit[jid], split = (int)blockIdx.x - jobs.soff[jid];
     const DwJob jb = jobs.job[jid];
+    const int64_t ntiles = jobs.ntiles[jid];
+    const uint8_t* __restrict__ acts_base = jobs.acts[jid];
+    const uint8_t* __restrict__ dys_base = jobs.dys[jid];
     const int n_ot = jb.dy_slabs / 2;
     const int n_xs = jb.x1_slabs + jb.x2_slabs;
     const int n_xt = n_xs / 2;
@@ -591,8 +606,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #endif
 
 __global__ __launch_bounds__(512, 2)
-void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __restrict__ acts_base,
-                          const uint8_t* __restrict__ dys_base, float* __restrict__ slabs) {
+void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     constexpr int DEPTH = NERFHIP_DWF8_DEPTH;
     constexpr int MAXP = 36;                                   // pieces per stage: 2 tiles x (8 dY + 10 X) pairs
     constexpr int LPW = 5;                                     // piece DMAs per wave per stage (8 x 5 >= 36)
@@ -604,9 +618,12 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int jid = 0;
 #pragma unroll
-    for (int j = 1; j < kNumDwJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
+    for (int j = 1; j < kDwMaxJobs; ++j) jid += ((int)blockIdx.x >= jobs.soff[j]) ? 1 : 0;
     const int nsplit = jobs.nsplit[jid], split = (int)blockIdx.x - jobs.soff[jid];
     const DwJob jb = jobs.job[jid];
+    const int64_t ntiles = jobs.ntiles[jid];
+    const uint8_t* __restrict__ acts_base = jobs.acts[jid];
+    const uint8_t* __restrict__ dys_base = jobs.dys[jid];
     const int dyp = jb.dy_slabs / 2, x1p = jb.x1_slabs / 2, x2p = jb.x2_slabs / 2;
     const int n_ot = dyp, n_xt = x1p + x2p;
     const int np = dyp + n_xt;                                 // pieces per tile
@@ -730,75 +747,107 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, int64_t ntiles, const uint8_t* __rest
 
 
 struct GradTable {
-    float* w[12];
-    float* b[12];
+    float* w[kDwMaxJobs];     // per JOB: job j writes parameter tensor kDwJobs[j % 12].param of model j / 12
+    float* b[kDwMaxJobs];
 };
 
-// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients.
+// Adam fused into the reduce (single-GPU training step: no all-reduce sits between the gradients and the update).  A model's
+// parameters, exp_avg and exp_avg_sq live in flat fp32 buffers laid out exactly like its flat gradient buffer (optim.py
+// FlatAdam, ops.mlp_bwd), so gradient element e updates element e of each.  `state` = {step count, arrival ticket} as in
+// adam_kernel (optim.hip); nullptr = plain reduce.
+struct AdamFused {
+    float* param[kDwMaxModels];
+    float* m[kDwMaxModels];
+    float* v[kDwMaxModels];
+    const float* grad0[kDwMaxModels];     // base of the model's flat gradient buffer
+    float* state;
+    float lr, beta1, beta2, eps, wd;
+};
+
+// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients [and apply Adam].
 // One 256-thread block per (job, 32x32 tile): thread = one float4 (rows o..o+3 of one column) of the 1024-float
 // tile, summed over the job's splits with independent 16-B loads.
 // F8: operand rows/columns arrive in the order ds_read_b64_tr_b8 delivers them (m -> slab m >> 4, half (m >> 3) & 1, slot m & 7)
 // instead of natural feature order, and the bias partials hold one value per row.
 template <bool F8>
 __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, const float* __restrict__ slabs, GradTable G,
-                                                              int accumulate) {
+                                                              int accumulate, AdamFused A) {
     const int jid = blockIdx.y;
     const DwJob jb = jobs.job[jid];
+    const int model = jid / kNumDwJobs;
     const int nsplit = jobs.nsplit[jid], s0 = jobs.soff[jid];
     const int n_ot = jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
     const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
     const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
     const int ot = tile / (kDwMaxXTiles + 1), xt = tile % (kDwMaxXTiles + 1);
-    if (ot >= n_ot) return;
-    if (xt == kDwMaxXTiles) {                          // bias: lanes (m,0) + (m,1)
+    AdamCoef ac;
+    if (A.state) ac = adam_coef(A.state[0] + 1.0f, A.lr, A.beta1, A.beta2);
+    auto emit = [&](float* dst, float val) {
+        const float g = accumulate ? *dst + val : val;
+        *dst = g;
+        if (A.state) {
+            const size_t e = (size_t)(dst - A.grad0[model]);
+            adam_elem(A.param[model][e], g, A.m[model][e], A.v[model][e], ac, A.beta2, A.eps, A.wd);
+        }
+    };
+    if (ot < n_ot && xt == kDwMaxXTiles) {             // bias: lanes (m,0) + (m,1)
         const int m = threadIdx.x;
         if (m < 32) {
-            float s = 0.f;
+            float sacc = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) {
                 const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
-                s += F8 ? sl[m] : sl[m] + sl[m + 32];
+                sacc += F8 ? sl[m] : sl[m] + sl[m + 32];
             }
             const int o = F8 ? 32 * ot + chain_feature(m >> 4, f8_row_h(m & 15), f8_row_j(m & 15)) : 32 * ot + m;
-            if (o < n_out) G.b[jb.param][o] = accumulate ? G.b[jb.param][o] + s : s;
+            if (o < n_out) emit(G.b[jid] + o, sacc);
         }
-        return;
-    }
-    if (xt >= n_xt) return;
-    const int e4 = threadIdx.x;                        // floats 4*e4 .. 4*e4+3 of the tile: lane = e4>>2, r = 4*(e4&3)+k
-    const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
-                                                        ((size_t)(ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (ot < n_ot && xt < n_xt) {
+        const int e4 = threadIdx.x;                    // floats 4*e4 .. 4*e4+3 of the tile: lane = e4>>2, r = 4*(e4&3)+k
+        const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
+                                                            ((size_t)(ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const float4 v = src[(size_t)sp * (kDwSlabFloats / 4)];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const int lane = e4 >> 2, rq = e4 & 3;
-    const int h = lane >> 5, ncol = lane & 31;
-    const int m0 = 8 * rq + 4 * h;                     // operand rows m0 .. m0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
-    // natural order: row m = feature 32 ot + m.  F8: m -> feature chain_feature(m >> 4, (m >> 3) & 1, m & 7) of the tile
-    const int o0 = F8 ? 32 * ot + chain_feature(m0 >> 4, f8_row_h(m0 & 15), f8_row_j(m0 & 15)) : 32 * ot + m0;   // k adds to (m & 3)
-    const int xi = 32 * xt + ncol;
-    int xs = xi >> 4;
-    const int i = xi & 15;
-    const int sh = F8 ? f8_row_h(i) : slab_nat_h(i), sj = F8 ? f8_row_j(i) : slab_nat_j(i);     // slot (h, j) inside slab xs
-    int enc, col0;
-    if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
-    else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
-    int col;
-    if (enc == 0) col = col0 + chain_feature(xs, sh, sj);
-    else {
-        const int ch = (enc == 1) ? xyz_slot_channel(xs, sh, sj) : dir_slot_channel(xs, sh, sj);
-        col = ch < 0 ? -1 : col0 + ch;
-    }
-    if (col >= 0 && col < ldw) {
-        const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 v = src[(size_t)sp * (kDwSlabFloats / 4)];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const int lane = e4 >> 2, rq = e4 & 3;
+        const int h = lane >> 5, ncol = lane & 31;
+        const int m0 = 8 * rq + 4 * h;                     // operand rows m0 .. m0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
+        // natural order: row m = feature 32 ot + m.  F8: m -> feature chain_feature(m >> 4, (m >> 3) & 1, m & 7) of the tile
+        const int o0 = F8 ? 32 * ot + chain_feature(m0 >> 4, f8_row_h(m0 & 15), f8_row_j(m0 & 15)) : 32 * ot + m0;   // k adds to (m & 3)
+        const int xi = 32 * xt + ncol;
+        int xs = xi >> 4;
+        const int i = xi & 15;
+        const int sh = F8 ? f8_row_h(i) : slab_nat_h(i), sj = F8 ? f8_row_j(i) : slab_nat_j(i);     // slot (h, j) inside slab xs
+        int enc, col0;
+        if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
+        else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
+        int col;
+        if (enc == 0) col = col0 + chain_feature(xs, sh, sj);
+        else {
+            const int ch = (enc == 1) ? xyz_slot_channel(xs, sh, sj) : dir_slot_channel(xs, sh, sj);
+            col = ch < 0 ? -1 : col0 + ch;
+        }
+        if (col >= 0 && col < ldw) {
+            const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int o = o0 + k;
-            if (o < n_out) {
-                float* dst = G.w[jb.param] + (size_t)o * ldw + col;
-                *dst = accumulate ? *dst + vals[k] : vals[k];
+            for (int k = 0; k < 4; ++k) {
+                const int o = o0 + k;
+                if (o < n_out) emit(G.w[jid] + (size_t)o * ldw + col, vals[k]);
+            }
+        }
+    }
+    if (A.state) {
+        // arrival ticket (as adam_kernel): the last workgroup of the launch advances the step counter, after every workgroup
+        // that uses it has read the old value
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* ticket = reinterpret_cast<unsigned*>(A.state + 1);
+            const unsigned prev = atomicAdd(ticket, 1u);
+            if (prev == gridDim.x * gridDim.y - 1) {
+                *ticket = 0u;
+                A.state[0] = A.state[0] + 1.0f;
             }
         }
     }
@@ -823,16 +872,22 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
     return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
 }
 
-// NERFHIP_DW_WGS / 12 splits per job (fewer for few tiles): EQUAL ring-iteration counts per workgroup.  Under load every
+// The split plan: which workgroup = which (job, point range).  EQUAL ring-iteration counts per workgroup: under load every
 // workgroup completes one stage per (loaded HBM latency / stages in flight) whatever the stage's size, so a workgroup's time
 // follows its iteration count, not its bytes — splits in proportion to the jobs' bytes (5 to 18 slab pairs per tile) measured
-// 306 / 290 / 268 us at 512 / 768 / 1024 workgroups against 225-232 us for this plan (1024 x 192 points).
+// 306 / 290 / 268 us at 512 / 768 / 1024 workgroups against 225-232 us for equal iteration counts (1024 x 192 points).
 // e4m3 kernel: ONE round of the 256 CUs (measured at 1024 x 192: 207-215 us vs 233-247 us for 384-768 workgroups, and half the
 // split-K partials for the reduce kernel: 23 -> 12.5 us); the bf16 kernel does not care (440 us either way), the fp32 one
 // prefers two rounds (2,882 vs 3,244 us).
+// Several models in one launch (a training step's fine + coarse network): the workgroups are shared out so that the iteration
+// counts stay equal ACROSS the models — a model with a third of the points gets a third of the splits per job — instead of a
+// second, short launch that cannot hide its pipeline fill (coarse pass alone: 0.49 of the HBM peak vs 0.62 for the fine pass).
 #ifndef NERFHIP_DWF8_WGS
 #define NERFHIP_DWF8_WGS 256
 #endif
+#ifndef NERFHIP_DW_MIN_ITERS
+#define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
+#endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
 static int dw_target_wgs(int dtype) {
     static const int env = [] {
         const char* e = getenv("NERFHIP_DW_WGS");            // experiments only
@@ -840,96 +895,163 @@ static int dw_target_wgs(int dtype) {
     }();
     return env > 0 ? env : (dtype == NERFHIP_BF16_F8 ? NERFHIP_DWF8_WGS : NERFHIP_DW_WGS);
 }
-static int dw_plan(int64_t n_points, int dtype, nerfhip::DwJobTable* jt) {
+// n_points[m] points of model m (m < n_models).  Fills jt (nsplit, soff, job, ntiles, njobs; the tensor pointers are the
+// caller's) when non-null; returns the number of workgroups = partial slabs.
+static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::DwJobTable* jt) {
+    using namespace nerfhip;
     using namespace nerfhip::mlp;
-    const int64_t tiles = act_tiles(n_points, dtype) / (dtype == NERFHIP_BF16_F8 ? 2 : 1);   // f8: units of work are tile PAIRS
-    int off = 0;
-    for (int j = 0; j < kNumDwJobs; ++j) {
-        const int target = dw_target_wgs(dtype);
-        int64_t ns = target / kNumDwJobs + (j >= 1 && j <= target % kNumDwJobs ? 1 : 0);   // remainder: to the 256 x 256 jobs
-#ifndef NERFHIP_DW_MIN_ITERS
-#define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
-#endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
-        if (NERFHIP_DW_MIN_ITERS > 0 && ns > tiles / NERFHIP_DW_MIN_ITERS) ns = tiles / NERFHIP_DW_MIN_ITERS;
-        if (ns > tiles) ns = tiles;
-        if (ns < 1) ns = 1;
-        if (jt) {
-            jt->job[j] = kDwJobs[j];
-            jt->nsplit[j] = (int)ns;
-            jt->soff[j] = off;
-        }
-        off += (int)ns;
+    const int njobs = n_models * kNumDwJobs;
+    int64_t units[kDwMaxJobs];     // ring iterations of a job if it were one workgroup (f8: tile PAIRS)
+    int64_t cap[kDwMaxJobs];
+    int ns[kDwMaxJobs];
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const int64_t tiles = act_tiles(n_points[j / kNumDwJobs], dtype);
+        units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
+        cap[j] = NERFHIP_DW_MIN_ITERS > 0 ? units[j] / NERFHIP_DW_MIN_ITERS : units[j];
+        if (cap[j] > units[j]) cap[j] = units[j];
+        if (cap[j] < 1) cap[j] = 1;
+        ns[j] = 1;
+        ++total;
     }
-    if (jt) jt->soff[kNumDwJobs] = off;
-    return off;
+    // greedy: the next workgroup goes to the job whose workgroups currently run the most iterations; ties go to the jobs with
+    // the most bytes per iteration (the 256 x 256 layers, jobs 1..8 of a model), then to the lower index
+    const int target = dw_target_wgs(dtype);
+    while (total < target) {
+        int best = -1;
+        for (int j = 0; j < njobs; ++j) {
+            if (ns[j] >= cap[j]) continue;
+            if (best < 0) { best = j; continue; }
+            const int64_t a = units[j] * ns[best], b = units[best] * ns[j];          // units[j]/ns[j]  vs  units[best]/ns[best]
+            const int jj = j % kNumDwJobs, bb = best % kNumDwJobs;
+            const bool j_big = jj >= 1 && jj <= 8, b_big = bb >= 1 && bb <= 8;
+            if (a > b || (a == b && j_big && !b_big)) best = j;
+        }
+        if (best < 0) break;
+        ++ns[best];
+        ++total;
+    }
+    if (jt) {
+        int off = 0;
+        for (int j = 0; j < kDwMaxJobs; ++j) {
+            const int jj = j < njobs ? j : 0;
+            jt->job[j] = kDwJobs[jj % kNumDwJobs];
+            jt->nsplit[j] = j < njobs ? ns[j] : 0;
+            jt->soff[j] = off;
+            jt->ntiles[j] = act_tiles(n_points[jj / kNumDwJobs], dtype);
+            if (j < njobs) off += ns[j];
+        }
+        jt->soff[kDwMaxJobs] = off;
+        jt->njobs = njobs;
+    }
+    return total;
 }
 
 extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {      // total (job, split) workgroups / partial slabs
     if (n_points <= 0 || !valid_dtype(dtype)) return 0;
-    return dw_plan(n_points, dtype, nullptr);
+    return dw_plan(&n_points, 1, dtype, nullptr);
 }
-
 extern "C" size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype) {
     return (size_t)nerfhip_mlp_dw_splits(n_points, dtype) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
 }
+extern "C" size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_host, int n_models, int dtype) {
+    if (!n_points_host || n_models < 1 || n_models > nerfhip::kDwMaxModels || !valid_dtype(dtype)) return 0;
+    for (int m = 0; m < n_models; ++m)
+        if (n_points_host[m] <= 0) return 0;
+    return (size_t)dw_plan(n_points_host, n_models, dtype, nullptr) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+}
 
-extern "C" int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
-                                      const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
-                                      float* const* grad_b_host, int accumulate, int dtype, int phases,
-                                      nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(n >= 0);
-    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
-    NERFHIP_CHECK_ARG(grad_w_host && grad_b_host);
-    nerfhip::GradTable G;
-    for (int i = 0; i < 12; ++i) {
-        NERFHIP_CHECK_ARG(grad_w_host[i] && grad_b_host[i]);
-        G.w[i] = grad_w_host[i];
-        G.b[i] = grad_b_host[i];
-    }
-    if (n == 0) return 0;
-    NERFHIP_CHECK_ARG(g_out && out && packed_bwd && acts && dys && dw_workspace);
-    if ((((uintptr_t)g_out) | ((uintptr_t)out) | ((uintptr_t)packed_bwd) | ((uintptr_t)acts) | ((uintptr_t)dys)) & 15)
-        return NERFHIP_E_ALIGN;
-    hipStream_t s = (hipStream_t)stream;
+// chain launch of one model
+static void launch_chain(const float* g_out, const float* g_scale, const float* out, int64_t n, const void* packed_bwd,
+                         const void* acts, void* dys, int dtype, hipStream_t s) {
     const int64_t tiles = act_tiles(n, dtype);
+    if (dtype == NERFHIP_BF16_F8)
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, g_scale,
+                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+    else if (dtype == NERFHIP_BF16)
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
+                           g_scale, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+    else
+        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, g_scale,
+                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+}
+
+extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const float* const* out_host,
+                                     const int64_t* n_host, const void* const* packed_bwd_host, const void* const* acts_host,
+                                     void* const* dys_host, void* dw_workspace, float* const* grad_w_host,
+                                     float* const* grad_b_host, int accumulate, int dtype, int phases, const float* g_scale,
+                                     const nerfhip_adam_fused* adam, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(n_models >= 1 && n_models <= nerfhip::kDwMaxModels);
+    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
+    NERFHIP_CHECK_ARG(g_out_host && out_host && n_host && packed_bwd_host && acts_host && dys_host && grad_w_host && grad_b_host);
+    NERFHIP_CHECK_ARG(!(adam && accumulate));
+    nerfhip::GradTable G;
     nerfhip::DwJobTable jt;
-    const int nwg = dw_plan(n, dtype, &jt);
-    const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), nerfhip::mlp::kNumDwJobs);
+    for (int m = 0; m < n_models; ++m) {
+        NERFHIP_CHECK_ARG(n_host[m] > 0);           // (an empty batch launches nothing: the single-model entry point handles it)
+        NERFHIP_CHECK_ARG(g_out_host[m] && out_host[m] && packed_bwd_host[m] && acts_host[m] && dys_host[m] && dw_workspace);
+        if ((((uintptr_t)g_out_host[m]) | ((uintptr_t)out_host[m]) | ((uintptr_t)packed_bwd_host[m]) | ((uintptr_t)acts_host[m]) |
+             ((uintptr_t)dys_host[m])) & 15)
+            return NERFHIP_E_ALIGN;
+    }
+    const int nwg = dw_plan(n_host, n_models, dtype, &jt);
+    for (int j = 0; j < nerfhip::kDwMaxJobs; ++j) {
+        const int jj = j < jt.njobs ? j : 0, m = jj / nerfhip::mlp::kNumDwJobs, prm = nerfhip::mlp::kDwJobs[jj % nerfhip::mlp::kNumDwJobs].param;
+        NERFHIP_CHECK_ARG(grad_w_host[12 * m + prm] && grad_b_host[12 * m + prm]);
+        G.w[j] = grad_w_host[12 * m + prm];
+        G.b[j] = grad_b_host[12 * m + prm];
+        jt.acts[j] = (const uint8_t*)acts_host[m];
+        jt.dys[j] = (const uint8_t*)dys_host[m];
+    }
+    nerfhip::AdamFused A;
+    A.state = nullptr;
+    A.lr = A.beta1 = A.beta2 = A.eps = A.wd = 0.f;
+    for (int m = 0; m < nerfhip::kDwMaxModels; ++m) { A.param[m] = A.m[m] = A.v[m] = nullptr; A.grad0[m] = nullptr; }
+    if (adam) {
+        NERFHIP_CHECK_ARG(adam->state && adam->n_models == n_models);
+        for (int m = 0; m < n_models; ++m) {
+            NERFHIP_CHECK_ARG(adam->param[m] && adam->exp_avg[m] && adam->exp_avg_sq[m] && adam->grad_flat[m]);
+            A.param[m] = adam->param[m]; A.m[m] = adam->exp_avg[m]; A.v[m] = adam->exp_avg_sq[m]; A.grad0[m] = adam->grad_flat[m];
+        }
+        A.state = adam->state; A.lr = adam->lr; A.beta1 = adam->beta1; A.beta2 = adam->beta2; A.eps = adam->eps; A.wd = adam->weight_decay;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), (unsigned)jt.njobs);
     const bool do_chain = phases & 1, do_dw = phases & 2, do_reduce = phases & 4;
-    if (dtype == NERFHIP_BF16_F8) {
-        if (do_chain)
-            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s,
-                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        if (do_dw)
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, tiles, (const uint8_t*)acts,
-                               (const uint8_t*)dys, (float*)dw_workspace);
-        if (do_reduce)
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
-        return nerfhip_launch_status();
+    if (do_chain)
+        for (int m = 0; m < n_models; ++m) launch_chain(g_out_host[m], g_scale, out_host[m], n_host[m], packed_bwd_host[m], acts_host[m], dys_host[m], dtype, s);
+    if (do_dw) {
+        if (dtype == NERFHIP_BF16_F8)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, (float*)dw_workspace);
+        else if (dtype == NERFHIP_BF16)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, (float*)dw_workspace);
+        else
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, (float*)dw_workspace);
     }
-    if (dtype == NERFHIP_BF16) {
-        if (do_chain)
-            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s,
-                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        if (do_dw)
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_BF16>, dim3(nwg), dim3(512), 0, s, jt, tiles,
-                               (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
-    } else {
-        if (do_chain)
-            hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s,
-                               g_out, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-        if (do_dw)
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_kernel<NERFHIP_F32>, dim3(nwg), dim3(512), 0, s, jt, tiles,
-                               (const uint8_t*)acts, (const uint8_t*)dys, (float*)dw_workspace);
+    if (do_reduce) {
+        if (dtype == NERFHIP_BF16_F8)
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate, A);
+        else
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate, A);
     }
-    if (do_reduce)
-        hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate);
     return nerfhip_launch_status();
 }
 
-extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd,
-                               const void* acts, void* dys, void* dw_workspace, float* const* grad_w_host,
-                               float* const* grad_b_host, int accumulate, int dtype, nerfhip_stream_t stream) {
-    return nerfhip_mlp_bwd_phases(g_out, out, n, packed_bwd, acts, dys, dw_workspace, grad_w_host, grad_b_host, accumulate,
-                                  dtype, 7, stream);
+extern "C" int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
+                                      void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
+                                      int accumulate, int dtype, int phases, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(n >= 0);
+    if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
+    NERFHIP_CHECK_ARG(grad_w_host && grad_b_host);
+    for (int i = 0; i < 12; ++i) NERFHIP_CHECK_ARG(grad_w_host[i] && grad_b_host[i]);
+    if (n == 0) return 0;
+    return nerfhip_mlp_bwd_multi(1, &g_out, &out, &n, &packed_bwd, &acts, &dys, dw_workspace, grad_w_host, grad_b_host, accumulate,
+                                 dtype, phases, nullptr, nullptr, stream);
+}
+
+extern "C" int nerfhip_mlp_bwd(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
+                               void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,
+                               int accumulate, int dtype, nerfhip_stream_t stream) {
+    return nerfhip_mlp_bwd_phases(g_out, out, n, packed_bwd, acts, dys, dw_workspace, grad_w_host, grad_b_host, accumulate, dtype, 7,
+                                  stream);
 }

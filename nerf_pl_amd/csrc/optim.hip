@@ -11,7 +11,7 @@
 //
 // HBM-bound: 16 B read + 12 B written per element, float4 per thread.  The step counter is advanced by the LAST
 // workgroup to finish (arrival ticket), i.e. after every workgroup has read the old value.
-#include "common.h"
+#include "adam_math.h"
 
 namespace nerfhip {
 
@@ -41,9 +41,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(AdamTable T, float* 
     const float* __restrict__ G = T.grad[ti];
     float* __restrict__ M = T.m[ti];
     float* __restrict__ V = T.v[ti];
-    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    const float step_size = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
-    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    const AdamCoef ac = adam_coef(t, lr, beta1, beta2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t i = base + ((int64_t)r * kAdamThreads + threadIdx.x) * kAdamVec;
@@ -52,26 +50,14 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(AdamTable T, float* 
             float4 m = *reinterpret_cast<const float4*>(M + i), v = *reinterpret_cast<const float4*>(V + i);
             float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gg = gp[k] + wd * pp[k];
-                mp[k] = mp[k] + (gg - mp[k]) * omb1;
-                vp[k] = vp[k] * beta2 + omb2 * gg * gg;
-                pp[k] = pp[k] - step_size * (mp[k] / (sqrtf(vp[k]) * rs2 + eps));
-            }
+            for (int k = 0; k < 4; ++k) adam_elem(pp[k], gp[k], mp[k], vp[k], ac, beta2, eps, wd);
             *reinterpret_cast<float4*>(P + i) = p;
             *reinterpret_cast<float4*>(M + i) = m;
             *reinterpret_cast<float4*>(V + i) = v;
         } else {
             for (int k = 0; k < kAdamVec; ++k) {
                 const int64_t j = i + k;
-                if (j < n) {
-                    const float gg = G[j] + wd * P[j];
-                    const float m = M[j] + (gg - M[j]) * omb1;
-                    const float v = V[j] * beta2 + omb2 * gg * gg;
-                    M[j] = m;
-                    V[j] = v;
-                    P[j] = P[j] - step_size * (m / (sqrtf(v) * rs2 + eps));
-                }
+                if (j < n) adam_elem(P[j], G[j], M[j], V[j], ac, beta2, eps, wd);
             }
         }
     }

@@ -126,6 +126,13 @@ class NeRF(nn.Module):
         ops.pack_weights_bwd_raw(wp, buf, dtype)
         return buf
 
+    def train_buffers(self, dtype, dev):
+        """(forward image buffer, W^T image buffer) of this model, allocated once per (dtype, device)."""
+        buf = self._packed_cache.get(dtype)
+        if buf is None or buf.device != dev:
+            buf = self._packed_cache[dtype] = torch.empty(ops.packed_bytes(dtype), device=dev, dtype=torch.uint8)
+        return buf, self._bwd_buffer(dtype, dev)
+
     def packed_weights_train(self, dtype=None):
         """(forward image, W^T image) of the current parameters in ONE launch: a training forward packs both, its backward
         (same weights: autograd forbids changing them in between) reuses the second."""

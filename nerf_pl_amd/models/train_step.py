@@ -1,0 +1,126 @@
+"""The training step's render + loss as ONE autograd node ("fused loss + PSNR + composite backward seed").
+
+`render_rays` (models/rendering.py) stays the modular, drop-in boundary: every operator an autograd node of its own, any loss
+on top.  `NeRFSystem.training_step` (train.py:103-117) however always composes the same graph — render_rays -> MSELoss ->
+backward -> Adam — and at ~1 ms per step the ~30 small launches and node hops of the modular form are 10-15 % of it.  This
+module runs that exact computation with the launches a fixed recipe allows:
+
+    forward   4 RNG draws (the reference's, same order: rendering.py:203, :152, :39, :152)
+              1 launch   both models' weight images (forward + W^T)                     nerfhip_mlp_pack_weights_train_multi
+              per pass   z sampling, fused MLP forward (saving), compositing + d MSE / d rgb + compositing backward
+                                                                                          nerfhip_composite_train
+              1 launch   loss value + PSNR                                               nerfhip_mse_psnr (values only)
+    backward  per model its chain kernel, then ONE weight-gradient launch and ONE reduce launch for BOTH models
+              (optionally with the Adam update applied in the reduce)                    nerfhip_mlp_bwd_multi
+
+Every kernel forms its values with the same expressions as the modular path, so loss, outputs and d loss / d raw are
+bit-identical to it; the parameter gradients differ only in the fp32 summation order of the split-K partials.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def fusable(models, embeddings, loss_mod):
+    from ..losses import MSELoss
+    from .rendering import _fusable
+    return (isinstance(loss_mod, MSELoss) and _fusable(models, embeddings)
+            and len({m.mlp_dtype for m in models}) == 1
+            and all(p.requires_grad for m in models for p in m.parameters()))
+
+
+class _TrainRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, rays, rgbs, *params):
+        models, S, use_disp, perturb, noise_std, N, white_back, adam = cfg
+        rays = rays.float().contiguous()
+        rgbs = rgbs.float().contiguous()
+        B = rays.shape[0]
+        dev = rays.device
+        dtype = models[0].mlp_dtype
+        # RNG: the reference's four draws, same order / shapes / device — issued first, consumed below
+        perturb_rand = torch.rand(B, S, device=dev) if perturb > 0 else None               # rendering.py:203
+        noise_c = torch.randn(B, S, device=dev)                                            # :152 (always drawn)
+        u = torch.rand(B, N, device=dev) if (N > 0 and perturb != 0) else None             # :39
+        noise_f = torch.randn(B, S + N, device=dev) if N > 0 else None                     # :152
+        packs = ops.pack_models_train(models, dtype)
+        # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`
+        gscale = float(np.float32(2.0) / np.float32(3 * B))
+        z = ops.sample_coarse_z(rays, S, use_disp, perturb, perturb_rand)                  # :189-204
+        acts_c = ops.alloc_acts(z.numel(), dtype, dev)
+        raw_c = ops.mlp_fwd_rays(rays, z, packs[0][0], False, dtype, save=acts_c)
+        w_c, opac_c, rgb_c, depth_c, g_raw_c = ops.composite_train(raw_c, z, rays, noise_c, noise_std, white_back, rgbs, gscale,
+                                                                   want_weights=N > 0)
+        entries = [(g_raw_c, raw_c, packs[0][1], acts_c)]
+        outs = [rgb_c, depth_c, opac_c]
+        rgb_f = None
+        if N > 0:
+            zf = ops.fine_z(z, w_c, N, u=u)                                                # :223-229
+            acts_f = ops.alloc_acts(zf.numel(), dtype, dev)
+            raw_f = ops.mlp_fwd_rays(rays, zf, packs[1][0], False, dtype, save=acts_f)
+            _, opac_f, rgb_f, depth_f, g_raw_f = ops.composite_train(raw_f, zf, rays, noise_f, noise_std, white_back, rgbs, gscale,
+                                                                     want_weights=False)
+            entries.insert(0, (g_raw_f, raw_f, packs[1][1], acts_f))                      # fine model first (as autograd would)
+            outs += [rgb_f, depth_f, opac_f]
+        out3 = ops.mse_psnr_values(rgb_c, rgb_f, rgbs)                                     # losses.py:9-14, metrics.py:4-13
+        ctx.models = [models[1], models[0]] if N > 0 else [models[0]]
+        ctx.entries, ctx.dtype, ctx.adam = entries, dtype, adam
+        ctx.n_params = [len(m.flat_params()) for m in models]
+        ctx.mark_non_differentiable(out3, *outs)
+        ctx.set_materialize_grads(False)
+        return (out3[0], out3) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        n_models = len(ctx.n_params)
+        if g_loss is None:
+            return (None, None, None) + (None,) * sum(ctx.n_params)
+        entries = ctx.entries
+        # d L / d loss multiplies every g_out INSIDE the chain kernels (a device scalar): no scaling launches, whatever the
+        # caller passed to backward()
+        g_scale = None if ops.is_unit_seed(g_loss) else g_loss.reshape(1).float().contiguous()
+        models, dtype = ctx.models, ctx.dtype
+        hooked = any(getattr(m, "_grad_ready_hook", None) is not None for m in models)
+        if hooked:
+            # N > 1 ranks: per model chain -> dW -> reduce -> grad-ready hook, so that the fine model's all-reduce travels
+            # while the coarse model's backward still runs (parallel.GradSync)
+            grads = []
+            for m, (g_out, out, packed_bwd, acts) in zip(models, entries):
+                ((gw, gb, flat),) = ops.mlp_bwd_multi([(g_out, out, packed_bwd, acts)], dtype, g_scale=g_scale)
+                m._flat_grad = flat
+                m._grad_ready_hook(m, flat)
+                grads.append((gw, gb, flat))
+        else:
+            adam = ctx.adam.handle(models) if ctx.adam is not None else None
+            grads = ops.mlp_bwd_multi(entries, dtype, adam=adam, g_scale=g_scale)
+            for m, g in zip(models, grads):
+                m._flat_grad = g[2]
+            if ctx.adam is not None:
+                ctx.adam.applied_in_backward(models)
+        ctx.entries = None
+        by_model = {id(m): g for m, g in zip(models, grads)}
+        out = []
+        order = [models[-1]] + models[:-1] if n_models == 2 else models        # parameter order of forward(): coarse, fine
+        for m in order:
+            gw, gb, _ = by_model[id(m)]
+            out += gw + gb
+        return (None, None, None) + tuple(out)
+
+
+def render_rays_train(models, embeddings, rays, rgbs, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
+                      white_back=False, adam=None):
+    """Training-mode `render_rays` + MSELoss + PSNR for one ray chunk.  Returns (results, loss, out3): `results` has the keys
+    of render_rays (rendering.py:213-244; detached values: the only differentiable output is `loss`, whose backward produces
+    the gradients of every parameter of `models`), out3 = [loss, psnr, mse] detached.
+    adam: an optim.FlatAdam to apply inside the backward's reduce kernel (single-GPU steps; `optimizer.step()` then skips)."""
+    N = int(N_importance)
+    use = list(models[:2]) if N > 0 else [models[0]]
+    params = [p for m in use for p in m.flat_params()]
+    cfg = (use, int(N_samples), bool(use_disp), float(perturb), float(noise_std), N, bool(white_back), adam)
+    res = _TrainRender.apply(cfg, rays, rgbs, *params)
+    loss, out3 = res[0], res[1]
+    results = {'rgb_coarse': res[2], 'depth_coarse': res[3], 'opacity_coarse': res[4]}
+    if N > 0:
+        results.update(rgb_fine=res[5], depth_fine=res[6], opacity_fine=res[7])
+    return results, loss, out3

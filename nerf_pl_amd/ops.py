@@ -204,6 +204,32 @@ def composite(raw, z, rays, noise=None, noise_std=0.0, white_back=False):
     return _Composite.apply(raw, z, rays, noise, float(noise_std), bool(white_back))
 
 
+@device_guard
+def composite_train(raw, z, rays, noise, noise_std, white_back, target, grad_scale, want_weights=True):
+    """composite (raw (B,S,4)) + d MSE / d rgb against `target` (B,3) + the compositing backward for it, one launch
+    (nerfhip_composite_train).  Returns (weights | None, opacity, rgb, depth, g_raw = d loss / d raw); nothing is recorded for
+    autograd — the caller (models/train_step.py) owns the backward."""
+    require_gpu(raw, z, rays, noise, target)
+    raw, z, rays, target = _c(raw), _c(z), _c(rays), _c(target)
+    B, S = z.shape
+    if raw.numel() != B * S * 4 or target.numel() != B * 3:
+        raise ValueError("composite_train: raw must be (B,S,4) and target (B,3)")
+    if noise_std == 0:
+        noise = None
+    elif noise is not None:
+        noise = _c(noise)
+    dev = z.device
+    weights = torch.empty(B, S, device=dev, dtype=torch.float32) if want_weights else None
+    opacity = torch.empty(B, device=dev, dtype=torch.float32)
+    rgb = torch.empty(B, 3, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, device=dev, dtype=torch.float32)
+    g_raw = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+    check(_lib.load().nerfhip_composite_train(ptr(raw), ptr(z), ptr(rays), ptr(noise), float(noise_std), int(bool(white_back)),
+                                              ptr(target), float(grad_scale), ptr(weights), ptr(rgb), ptr(depth), ptr(opacity),
+                                              ptr(g_raw), B, S, stream_ptr()), "nerfhip_composite_train")
+    return weights, opacity, rgb, depth, g_raw
+
+
 # ------------------------------------------------------------------------------- loss + PSNR (N2)
 class _MsePsnr(torch.autograd.Function):
     @staticmethod
@@ -229,10 +255,42 @@ class _MsePsnr(torch.autograd.Function):
         g_c, g_f = ctx.saved_tensors
         if g_loss is None:
             return None, None, None
+        if is_unit_seed(g_loss):              # d loss / d loss == 1 (loss.backward(unit_seed(loss))): no scaling launch
+            return g_c, g_f, None
         if g_f is None:
             return g_c * g_loss, None, None
         g_c, g_f = torch._foreach_mul([g_c, g_f], g_loss)      # one launch for both images
         return g_c, g_f, None
+
+
+_UNIT_SEEDS = {}
+
+
+def unit_seed(like):
+    """A cached scalar 1.0 on `like`'s device to pass as `loss.backward(unit_seed(loss))`: the fused backward nodes recognise it
+    (by storage) and skip the multiplication by d loss / d loss.  Never modify it in place."""
+    key = (like.device.type, like.device.index)
+    t = _UNIT_SEEDS.get(key)
+    if t is None:
+        t = _UNIT_SEEDS[key] = torch.ones((), device=like.device, dtype=torch.float32)
+    return t
+
+
+def is_unit_seed(g):
+    t = _UNIT_SEEDS.get((g.device.type, g.device.index))
+    return t is not None and g.data_ptr() == t.data_ptr() and g.numel() == 1
+
+
+@device_guard
+def mse_psnr_values(rgb_coarse, rgb_fine, target):
+    """[loss, psnr, mse] (losses.py:9-14 + metrics.py:4-13) without gradients: the value half of nerfhip_mse_psnr."""
+    require_gpu(rgb_coarse, rgb_fine, target)
+    rgb_coarse, target = _c(rgb_coarse), _c(target)
+    rgb_fine = _c(rgb_fine) if rgb_fine is not None else None
+    out3 = torch.empty(3, device=target.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_mse_psnr(ptr(rgb_coarse), ptr(rgb_fine), ptr(target), target.numel(), ptr(out3), None, None, stream_ptr()),
+          "nerfhip_mse_psnr")
+    return out3
 
 
 @device_guard
@@ -413,3 +471,85 @@ def mlp_dx_embedded(dys, n, w_xyz1, w_xyz5, w_dir, dtype):
     check(_lib.load().nerfhip_mlp_dx_embedded(ptr(dys), n, ptr(_c(w_xyz1.detach())), ptr(_c(w_xyz5.detach())), ptr(_c(w_dir.detach())),
                                               ptr(gx), 90, code, stream_ptr()), "nerfhip_mlp_dx_embedded")
     return gx
+
+
+# ------------------------------------------------------------------------------- several models per launch (training step)
+def pack_models_train(models, dtype):
+    """Forward + W^T images of every model in ONE launch (nerfhip_mlp_pack_weights_train_multi).  Returns [(packed, packed_bwd)]
+    in the models' cached buffers (NeRF.packed_weights_train's)."""
+    if not 1 <= len(models) <= 4:
+        raise ValueError("pack_models_train packs 1..4 models")
+    tabs, bufs = [], []
+    for m in models:
+        if not m.is_default_arch():
+            raise NotImplementedError("the fused HIP MLP implements the reference's default architecture only")
+        wp, bp, dev = m._pack_args()
+        tabs.append((wp, bp))
+        bufs.append(m.train_buffers(dtype, dev))
+    n = len(models)
+    W = (ctypes.c_void_p * (12 * n))(*[t[0][i] for t in tabs for i in range(12)])
+    Bv = (ctypes.c_void_p * (12 * n))(*[t[1][i] for t in tabs for i in range(12)])
+    P = (ctypes.c_void_p * n)(*[b[0].data_ptr() for b in bufs])
+    Pb = (ctypes.c_void_p * n)(*[b[1].data_ptr() for b in bufs])
+    with torch.cuda.device(bufs[0][0].device):
+        check(_lib.load().nerfhip_mlp_pack_weights_train_multi(W, Bv, P, Pb, n, mlp_dtype_code(dtype), stream_ptr()),
+              "nerfhip_mlp_pack_weights_train_multi")
+    return bufs
+
+
+def flat_grad_views(n_points, device, shapes=PARAM_SHAPES):
+    """One flat fp32 buffer for a model's 24 gradients + the 12 weight and 12 bias views of it (the layout FlatAdam mirrors)."""
+    sizes = [s[0] * s[1] for s in shapes] + [s[0] for s in shapes]
+    flat = (torch.zeros if n_points == 0 else torch.empty)(sum(sizes), device=device, dtype=torch.float32)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(flat[off:off + sz])
+        off += sz
+    return [v.view(s) for v, s in zip(views[:12], shapes)], views[12:], flat
+
+
+def mlp_bwd_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=None):
+    """Backward of several models with ONE dW launch and ONE reduce launch (nerfhip_mlp_bwd_multi).
+    entries: [(g_out (n,4), out (n,4), packed_bwd, acts)], n > 0.  adam: an _lib.AdamFused (the update then happens inside the
+    reduce kernel).  g_scale: device scalar multiplying every g_out inside the chain kernels (the upstream gradient of the loss).
+    Returns [(gw list, gb list, flat)] per model."""
+    code = mlp_dtype_code(dtype)
+    lib = _lib.load()
+    M = len(entries)
+    dev = entries[0][1].device
+    gs, outs, ns, dys, grads = [], [], [], [], []
+    for g_out, out, packed_bwd, acts in entries:
+        require_gpu(g_out, out)
+        g_out = _c(g_out.float()).reshape(-1, 4)
+        out = _c(out).reshape(-1, 4)
+        gs.append(g_out)
+        outs.append(out)
+        ns.append(out.shape[0])
+    with torch.cuda.device(dev):
+        n_arr = (ctypes.c_int64 * M)(*ns)
+        key = ("multi", tuple(ns), code)
+        if workspace is not None and key in workspace:
+            dys, ws = workspace[key]
+        else:
+            dys = [torch.empty(int(lib.nerfhip_mlp_dy_bytes(n, code)), device=dev, dtype=torch.uint8) for n in ns]
+            ws = torch.empty(int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, M, code)), device=dev, dtype=torch.uint8)
+            if workspace is not None:
+                workspace[key] = (dys, ws)
+        for n in ns:
+            grads.append(flat_grad_views(n, dev))
+        vp = ctypes.c_void_p
+        G = (vp * M)(*[t.data_ptr() for t in gs])
+        O = (vp * M)(*[t.data_ptr() for t in outs])
+        PB = (vp * M)(*[e[2].data_ptr() for e in entries])
+        AC = (vp * M)(*[e[3].data_ptr() for e in entries])
+        DY = (vp * M)(*[t.data_ptr() for t in dys])
+        GW = (vp * (12 * M))(*[t.data_ptr() for g in grads for t in g[0]])
+        GB = (vp * (12 * M))(*[t.data_ptr() for g in grads for t in g[1]])
+        if adam is not None:
+            for m in range(M):
+                adam.grad_flat[m] = grads[m][2].data_ptr()
+        if g_scale is not None:
+            require_gpu(g_scale)
+        check(lib.nerfhip_mlp_bwd_multi(M, G, O, n_arr, PB, AC, DY, ptr(ws), GW, GB, 0, code, int(phases), ptr(g_scale),
+                                        ctypes.addressof(adam) if adam is not None else None, stream_ptr()), "nerfhip_mlp_bwd_multi")
+    return grads

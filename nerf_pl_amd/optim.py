@@ -38,6 +38,7 @@ class FlatAdam(torch.optim.Optimizer):
         # [step count (float), arrival ticket (uint32 bits)] — device-resident: graph replays advance the counter
         self.dev_state = torch.zeros(2, device=dev, dtype=torch.float32)
         self._tables = None
+        self._applied = None          # ids of the models whose update the last backward already applied (fused reduce + Adam)
 
     # ---------------------------------------------------------------------------------------------- flat storage
     @staticmethod
@@ -100,6 +101,28 @@ class FlatAdam(torch.optim.Optimizer):
             else:
                 flat.grad = None
 
+    # ---------------------------------------------------------------------------------------------- update inside the backward
+    def handle(self, models):
+        """nerfhip_adam_fused for `models` (in that order): the fused training step's reduce kernel applies this optimizer's
+        update to the flat parameter storage while it writes the gradients (models/train_step.py; single-GPU steps only —
+        with several ranks the all-reduce sits between gradients and update)."""
+        self._check_alias()
+        h = _lib.AdamFused()
+        h.n_models = len(models)
+        for k, m in enumerate(models):
+            i = next(j for j, mm in enumerate(self.models) if mm is m)
+            h.param[k] = self.flats[i].data_ptr()
+            h.exp_avg[k] = self.exp_avg[i].data_ptr()
+            h.exp_avg_sq[k] = self.exp_avg_sq[i].data_ptr()
+        g = self.param_groups[0]
+        h.state = self.dev_state.data_ptr()
+        h.lr, h.beta1, h.beta2, h.eps, h.weight_decay = float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), \
+            float(g['weight_decay'])
+        return h
+
+    def applied_in_backward(self, models):
+        self._applied = {id(m) for m in models}
+
     # ---------------------------------------------------------------------------------------------- the update
     @torch.no_grad()
     def step(self, closure=None):
@@ -107,6 +130,12 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._applied is not None:
+            # the backward that produced these gradients already updated the parameters (and advanced the step counter)
+            done, self._applied = self._applied, None
+            if done != {id(m) for m in self.models}:
+                raise _lib.NerfHipError("FlatAdam: the fused backward updated only some of the optimizer's models")
+            return loss
         self._check_alias()
         self._gather_grads()
         idx = [i for i, f in enumerate(self.flats) if f.grad is not None]
@@ -127,6 +156,7 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     def zero_grad(self, set_to_none=True):
+        self._applied = None
         for m, flat in zip(self.models, self.flats):
             flat.grad = None
             m._flat_grad = None

@@ -89,10 +89,17 @@ class RayStore:
         return self.n_pixels
 
     def sample(self, batch_size, generator=None):
-        ids = torch.randint(0, self.n_pixels, (batch_size,), device=self.poses.device, generator=generator)
-        rays = gen_rays(self.poses, self.H, self.W, self.focal, self.near, self.far, pixel_ids=ids, use_ndc=self.use_ndc,
-                        ndc_near_plane=self.ndc_near_plane)
-        return {"rays": rays, "rgbs": self.rgbs[ids]}
+        """One training batch: pixel ids drawn on the GPU, their rays generated and their colours gathered in ONE launch
+        (nerfhip_sample_batch)."""
+        dev = self.poses.device
+        ids = torch.randint(0, self.n_pixels, (batch_size,), device=dev, generator=generator)
+        rays = torch.empty(batch_size, 8, device=dev, dtype=torch.float32)
+        rgbs = torch.empty(batch_size, 3, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(_lib.load().nerfhip_sample_batch(ptr(self.poses), ptr(ids), ptr(self.rgbs), int(batch_size), self.H, self.W,
+                                                   self.focal, self.near, self.far, int(self.use_ndc), self.ndc_near_plane, ptr(rays),
+                                                   ptr(rgbs), stream_ptr()), "nerfhip_sample_batch")
+        return {"rays": rays, "rgbs": rgbs}
 
     def image_rays(self, i):
         hw = self.H * self.W

@@ -48,6 +48,11 @@ class NeRFSystem(_Base):
         self.train_dataset = train_dataset
         self.val_dataset = val_dataset
         self.white_back = getattr(train_dataset, 'white_back', getattr(hparams, 'white_back', False))
+        # MI355X specifics (not in the reference): training_step runs render + loss as one autograd node
+        # (models/train_step.py) when the recipe allows it; `fuse_adam` additionally applies the FlatAdam update inside the
+        # backward's reduce kernel — only for single-GPU steps (no gradient all-reduce between backward and update)
+        self.fused_train_step = getattr(hparams, 'fused_train_step', True)
+        self.fuse_adam = False
 
     @property
     def hp(self):
@@ -112,16 +117,33 @@ class NeRFSystem(_Base):
         """train.py:103-117."""
         log = {'lr': get_learning_rate(self.optimizer)}
         rays, rgbs = self.decode_batch(batch)
-        results = self(rays)
-        log['train/loss'] = loss = self.loss(results, rgbs)
-        if getattr(self.loss, 'last', None) is not None:      # fused loss kernel already produced the PSNR
-            psnr_ = self.loss.last[1]
+        if self._fused_step_ok(rays):
+            from .models.train_step import render_rays_train
+            hp = self.hp
+            adam = self.optimizer if (self.fuse_adam and type(self.optimizer).__name__ == 'FlatAdam') else None
+            results, loss, out3 = render_rays_train(self.models, self.embeddings, rays, rgbs, hp.N_samples, hp.use_disp, hp.perturb,
+                                                    hp.noise_std, hp.N_importance, self.white_back, adam=adam)
+            self.loss.last = out3
+            log['train/loss'] = loss
+            psnr_ = out3[1]
         else:
-            typ = 'fine' if 'rgb_fine' in results else 'coarse'
-            with torch.no_grad():
-                psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
+            results = self(rays)
+            log['train/loss'] = loss = self.loss(results, rgbs)
+            if getattr(self.loss, 'last', None) is not None:      # fused loss kernel already produced the PSNR
+                psnr_ = self.loss.last[1]
+            else:
+                typ = 'fine' if 'rgb_fine' in results else 'coarse'
+                with torch.no_grad():
+                    psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
         log['train/psnr'] = psnr_
         return {'loss': loss, 'progress_bar': {'train_psnr': psnr_}, 'log': log}
+
+    def _fused_step_ok(self, rays):
+        if not (self.fused_train_step and torch.is_grad_enabled() and rays.is_cuda and rays.dim() == 2
+                and 0 < rays.shape[0] <= self.hp.chunk):
+            return False
+        from .models.train_step import fusable
+        return fusable(self.models, self.embeddings, self.loss)
 
     def validation_step(self, batch, batch_nb):
         """train.py:119-138 (image logging omitted: harness concern)."""
@@ -208,8 +230,9 @@ class GraphedTrainStep:
         out = self.system.training_step(batch, self.calls)
         self.opt.zero_grad(set_to_none=True)
         if self._seed is None:                 # created in an eager warm-up step, reused by every later (captured) one:
-            self._seed = torch.ones_like(out['loss'])        # spares the ones_like fill launch of a bare .backward()
-        out['loss'].backward(self._seed)
+            from .ops import unit_seed                       # spares the ones_like fill of a bare .backward(), and the fused
+            self._seed = unit_seed(out['loss']) if out['loss'].is_cuda else torch.ones_like(out['loss'])   # backward nodes
+        out['loss'].backward(self._seed)                     # recognise it: no multiplication by d loss / d loss either
         return self._detached(out)
 
     def _eager(self, batch):

@@ -1,0 +1,213 @@
+"""GPU: the fused training step (models/train_step.py, nerfhip_composite_train, nerfhip_mlp_bwd_multi, nerfhip_sample_batch,
+nerfhip_mlp_pack_weights_train_multi, Adam inside the reduce kernel) against the modular path it replaces — which is itself
+pinned to the reference (tests/test_gpu_training.py: reference-minted gradients) and to the oracle."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(dev, dtype, N_importance=64, perturb=1.0, noise_std=0.0, white_back=True, lr=5e-4, seeds=(5, 6)):
+    from nerf_pl_amd.system import NeRFSystem
+    hp = Namespace(N_samples=64, N_importance=N_importance, use_disp=False, perturb=perturb, noise_std=noise_std, chunk=1024 * 32,
+                   loss_type="mse", lr=lr, weight_decay=0, decay_step=[10 ** 6], decay_gamma=0.5, white_back=white_back)
+    system = NeRFSystem(hp)
+    system.nerf_coarse.load_state_dict(O.make_params(seeds[0], 4.0, 0.2))
+    if N_importance > 0:
+        system.nerf_fine.load_state_dict(O.make_params(seeds[1], 4.0, 0.2))
+    for m in system.models:
+        m.mlp_dtype = dtype
+    system = system.to(dev)
+    (opt,), _ = system.configure_optimizers()
+    return system, opt
+
+
+def _batch(dev, n=300, seed=3, kind="blender"):
+    g = torch.Generator().manual_seed(seed)
+    return {"rays": O.make_rays(seed, n, kind).to(dev), "rgbs": torch.rand(n, 3, generator=g).to(dev)}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_f8"])
+@pytest.mark.parametrize("cfg", [dict(), dict(N_importance=0), dict(noise_std=1.0, white_back=False, perturb=0.0)])
+def test_fused_step_equals_modular_step(dev, dtype, cfg):
+    """Same weights, batch and torch seed through the modular graph (render_rays -> MSELoss, one autograd node per operator)
+    and through the single fused node: loss, PSNR and every rendered output bit-identical; parameter gradients equal up to the
+    fp32 summation order of the split-K partials (one merged dW launch instead of one per model)."""
+    batch = _batch(dev, 300 if dtype != "fp32" else 130)
+    got = {}
+    for fused in (False, True):
+        system, opt = _system(dev, dtype, **cfg)
+        system.fused_train_step = fused
+        torch.manual_seed(11)
+        out = system.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        got[fused] = (out["loss"].detach().clone(), out["log"]["train/psnr"].detach().clone(),
+                      {n: p.grad.detach().clone() for n, p in system.named_parameters()})
+    assert torch.equal(got[False][0], got[True][0]), (got[False][0].item(), got[True][0].item())
+    assert torch.equal(got[False][1], got[True][1])
+    worst = 0.0
+    for n, g in got[False][2].items():
+        h = got[True][2][n]
+        assert torch.isfinite(h).all(), n
+        rel = (g - h).norm().item() / (g.norm().item() + 1e-20)
+        worst = max(worst, rel)
+        assert rel <= 2e-5, (dtype, cfg, n, rel)
+    print("fused vs modular step, %s %s: worst relative L2 difference of a gradient tensor %.2e" % (dtype, cfg, worst))
+
+
+def test_fused_step_outputs_equal_render_rays(dev):
+    """The values render_rays_train returns are the ones render_rays computes (same draws)."""
+    from nerf_pl_amd.models.rendering import render_rays
+    from nerf_pl_amd.models.train_step import render_rays_train
+    system, _ = _system(dev, "fp32", noise_std=1.0)
+    b = _batch(dev, 97)
+    torch.manual_seed(4)
+    res, loss, out3 = render_rays_train(system.models, system.embeddings, b["rays"], b["rgbs"], 64, False, 1.0, 1.0, 64, True)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        ref = render_rays(system.models, system.embeddings, b["rays"], 64, False, 1.0, 1.0, 64, 32768, True)
+    for k, v in ref.items():
+        assert torch.equal(res[k], v), k
+    mse_c = torch.mean((ref["rgb_coarse"] - b["rgbs"]) ** 2)
+    mse_f = torch.mean((ref["rgb_fine"] - b["rgbs"]) ** 2)
+    assert loss.item() == pytest.approx((mse_c + mse_f).item(), rel=1e-6)
+    assert out3[1].item() == pytest.approx((-10 * torch.log10(mse_f)).item(), rel=1e-6)
+
+
+@pytest.mark.parametrize("S", [64, 192, 70])
+@pytest.mark.parametrize("white_back,noise_std", [(True, 0.0), (False, 1.0)])
+def test_composite_train_is_bit_identical_to_the_three_launches(dev, S, white_back, noise_std):
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(S)
+    B = 37
+    raw = torch.randn(B, S, 4, generator=g).to(dev)
+    raw[..., :3] = torch.sigmoid(raw[..., :3])
+    raw[..., 3] = raw[..., 3] * 3 + 1
+    z = torch.sort(2 + 4 * torch.rand(B, S, generator=g), -1)[0].to(dev)
+    rays = O.make_rays(1, B, "blender").to(dev)
+    noise = torch.randn(B, S, generator=g).to(dev)
+    tgt = torch.rand(B, 3, generator=g).to(dev)
+    raw_m = raw.clone().requires_grad_(True)
+    w, opac, rgb, depth = ops.composite(raw_m, z, rays, noise, noise_std, white_back)
+    loss, _ = ops.mse_psnr(rgb, None, tgt)
+    loss.backward()
+    w2, opac2, rgb2, depth2, g_raw = ops.composite_train(raw, z, rays, noise, noise_std, white_back, tgt, float(np.float32(2.0) / np.float32(3 * B)))
+    for a, b in ((w, w2), (opac, opac2), (rgb, rgb2), (depth, depth2), (raw_m.grad, g_raw)):
+        assert torch.equal(a.detach(), b)
+
+
+def test_backward_seed_and_scaled_loss(dev):
+    """loss.backward() (autograd's ones), loss.backward(unit_seed) and (c * loss).backward() through the fused node: the upstream
+    gradient multiplies g_out inside the chain kernels."""
+    from nerf_pl_amd import ops
+    batch = _batch(dev, 128)
+    grads = {}
+    for mode in ("plain", "seed", "scaled"):
+        system, opt = _system(dev, "fp32", perturb=0.0)
+        out = system.training_step(batch, 0)
+        if mode == "plain":
+            out["loss"].backward()
+        elif mode == "seed":
+            out["loss"].backward(ops.unit_seed(out["loss"]))
+        else:
+            (out["loss"] * 0.5).backward()
+        grads[mode] = torch.cat([p.grad.flatten() for p in system.parameters()])
+    assert torch.equal(grads["plain"], grads["seed"])
+    assert torch.allclose(grads["scaled"], 0.5 * grads["plain"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16_f8"])
+def test_adam_inside_the_reduce_equals_a_separate_adam_launch(dev, dtype):
+    """`fuse_adam`: the reduce kernel applies FlatAdam's update while it writes the gradients; optimizer.step() then only
+    acknowledges it.  Same weights after 4 steps as with the separate nerfhip_adam_step launch (same expressions: adam_math.h),
+    same device-resident step counter, same exp_avg / exp_avg_sq."""
+    batch = _batch(dev, 200)
+    states = {}
+    for fuse in (False, True):
+        system, opt = _system(dev, dtype, perturb=0.0, lr=1e-3)
+        system.fuse_adam = fuse
+        for i in range(4):
+            out = system.training_step(batch, i)
+            opt.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            opt.step()
+        torch.cuda.synchronize()
+        states[fuse] = (torch.cat([p.detach().flatten() for p in system.parameters()]).clone(), opt.dev_state.clone(),
+                        torch.cat([e.flatten() for e in opt.exp_avg + opt.exp_avg_sq]).clone(),
+                        torch.cat([p.grad.flatten() for p in system.parameters()]).clone())
+    assert states[True][1][0].item() == 4.0 and states[False][1][0].item() == 4.0       # step counter
+    assert torch.allclose(states[True][3], states[False][3], rtol=1e-3, atol=1e-9)      # the gradients are still written
+    same = (states[True][0] == states[False][0]).float().mean().item()
+    print("parameters bit-identical after 4 steps: %.4f of 1.19 M" % same)
+    assert torch.allclose(states[True][0], states[False][0], rtol=1e-6, atol=1e-9)
+    assert torch.allclose(states[True][2], states[False][2], rtol=1e-6, atol=1e-12)
+
+
+def test_graphed_fused_step_with_adam_in_backward(dev):
+    """The whole fused step (batch drawn inside, Adam inside the reduce) captured as one hipGraph == the same step issued
+    eagerly, step for step."""
+    from nerf_pl_amd.system import GraphedTrainStep
+    gen = torch.Generator().manual_seed(1)
+    batches = [{"rays": O.make_rays(10 + i, 128, "blender").to(dev), "rgbs": torch.rand(128, 3, generator=gen).to(dev)}
+               for i in range(7)]
+    finals = []
+    for graphed in (False, True):
+        system, opt = _system(dev, "bf16_f8", perturb=0.0)
+        system.fuse_adam = True
+        stepper = GraphedTrainStep(system, opt, warmup=2 if graphed else 10 ** 9)
+        for b in batches:
+            stepper(b)
+        assert (stepper.graph is not None) == graphed
+        torch.cuda.synchronize()
+        finals.append((torch.cat([p.detach().flatten() for p in system.parameters()]).clone(), opt.dev_state[0].item()))
+    assert finals[0][1] == finals[1][1] == 7.0
+    assert torch.allclose(finals[0][0], finals[1][0], rtol=1e-5, atol=1e-7)
+
+
+def test_sample_batch_kernel_equals_gen_rays_plus_gather(dev):
+    from nerf_pl_amd.rays import RayStore, gen_rays
+    g = torch.Generator().manual_seed(0)
+    poses = torch.eye(4)[:3].repeat(3, 1, 1)
+    poses[:, :, 3] = torch.randn(3, 3, generator=g)
+    for ndc in (False, True):
+        store = RayStore(poses.to(dev), torch.rand(3, 20, 24, 3, generator=g).to(dev), 20, 24, 30.0, 2.0, 6.0, use_ndc=ndc)
+        gd = torch.Generator(device=dev).manual_seed(5)
+        b = store.sample(257, generator=gd)
+        gd = torch.Generator(device=dev).manual_seed(5)
+        ids = torch.randint(0, store.n_pixels, (257,), device=dev, generator=gd)
+        ref = gen_rays(store.poses, 20, 24, 30.0, 2.0, 6.0, pixel_ids=ids, use_ndc=ndc)
+        assert torch.equal(b["rays"], ref) and torch.equal(b["rgbs"], store.rgbs[ids])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pack_models_train_equals_per_model_packs(dev, dtype):
+    from nerf_pl_amd import ops
+    from tests.helpers import build_models
+    ms, _ = build_models([O.make_params(1), O.make_params(2)], dev, dtype)
+    want = [tuple(t.clone() for t in m.packed_weights_train(dtype)) for m in ms]
+    for m in ms:
+        for t in m.train_buffers(dtype, dev):
+            t.zero_()
+    got = ops.pack_models_train(ms, dtype)
+    for (a, b), (c, d) in zip(want, got):
+        assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_merged_dw_plan_shares_workgroups_in_proportion_to_points(dev):
+    """One dW launch for the fine (1024 x 192) and the coarse (1024 x 64) pass: the partial-slab count is that of ONE round of
+    the chip, not two launches' worth."""
+    import ctypes
+    from nerf_pl_amd import _lib
+    lib = _lib.load()
+    n = (ctypes.c_int64 * 2)(1024 * 192, 1024 * 64)
+    slab = 4 * (8 * 10 * 64 * 16 + 8 * 64)
+    merged = lib.nerfhip_mlp_dw_workspace_bytes_multi(n, 2, 2) // slab
+    single = lib.nerfhip_mlp_dw_workspace_bytes(1024 * 192, 2) // slab, lib.nerfhip_mlp_dw_workspace_bytes(1024 * 64, 2) // slab
+    assert single[0] == 256 and 240 <= merged <= 256 and merged < single[0] + single[1], (merged, single)

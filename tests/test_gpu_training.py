@@ -2,8 +2,8 @@
 the CPU oracle and against the gradient digests minted from the real reference.
 
 Tolerances: fp32 MFMA path 2e-4 of each tensor's max |grad| (different fp32 summation order over up to
-~10^4 points); bf16 path 4e-2 of max |grad| (bf16 activations + bf16 dY, fp32 accumulate) — bf16 is the
-roofline configuration, gated on PSNR rather than on gradient bits."""
+~10^4 points); reduced-precision paths: per-tensor gradient cosine >= 0.99 (bf16) / 0.98 (8-bit dW operands) — they are the
+roofline configurations, licensed by PSNR@step (tests/test_gpu_psnr_gate.py) rather than by gradient bits."""
 import pytest
 import torch
 
@@ -34,6 +34,7 @@ def test_mlp_backward_embedded_vs_autograd(dev, dtype, tol, n):
     out = m(x.to(dev))
     (out * g_out.to(dev)).sum().backward()
     assert (out.detach().cpu() - ref_out).abs().max().item() <= (1e-5 if dtype == "fp32" else 3e-2) * max(1.0, ref_out.abs().max().item())
+    worst = 1.0
     for name, prm in m.named_parameters():
         assert prm.grad is not None, name
         r = ref[name]
@@ -41,12 +42,17 @@ def test_mlp_backward_embedded_vs_autograd(dev, dtype, tol, n):
         if dtype == "fp32":
             err = (gq - r).abs().max().item()
             assert err <= tol * r.abs().max().item() + 1e-7, (dtype, n, name, err, r.abs().max().item())
-        else:   # bf16: relative L2 error of the whole tensor (rounding does not average out for tiny n)
-            # measured: 0.1-11% relative L2 (deepest layers worst), cosine >= 0.993, because the bf16
-            # FORWARD activations (hence ReLU gates) already differ from the fp32 oracle's
+        else:
+            # reduced precision: the DIRECTION of every gradient tensor (the bound of tests/test_gpu_bf16.py, here also at the
+            # ragged sizes n = 1, 33, 300): cosine >= 0.99 for bf16, >= 0.98 with the 8-bit dW operands; the relative L2 error
+            # (0.1-11 % measured, deepest layers worst: the bf16 FORWARD activations, hence ReLU gates, already differ from the
+            # fp32 oracle's) is printed, not gated
             rel = (gq - r).norm().item() / (r.norm().item() + 1e-12)
             cos = torch.nn.functional.cosine_similarity(gq.flatten(), r.flatten(), dim=0).item()
-            assert rel <= (0.30 if n < 64 else 0.16) and cos >= (0.95 if n < 64 else 0.985), (dtype, n, name, rel, cos)
+            worst = min(worst, cos)
+            assert cos >= (0.99 if dtype == "bf16" else 0.98), (dtype, n, name, rel, cos)
+    if dtype != "fp32":
+        print("worst per-tensor gradient cosine, %s n=%d: %.4f" % (dtype, n, worst))
 
 
 def test_f8_storage_gradients_track_bf16(dev):
