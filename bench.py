@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue the training step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fixed-batch", action="store_true", help="replay one resident batch instead of drawing a fresh one per step")
+    ap.add_argument("--modular-step", action="store_true",
+                    help="training_step through the modular autograd graph (render_rays -> MSELoss) instead of the fused node (A/B)")
+    ap.add_argument("--no-fuse-adam", action="store_true", help="N=1: keep Adam a separate launch instead of applying it in the reduce kernel")
     ap.add_argument("--no-extras", action="store_true", help="train mode: skip the eval / render / bf16-storage side measurements")
     ap.add_argument("--force-dist", action="store_true",
                     help="N=1: initialise the RCCL process group and route gradients through GradSync anyway (A/B of the N>1 step)")
@@ -248,10 +251,11 @@ def event_time(fn, reps, warm=3, graph=False):
     return sum(us) / len(us), us[0]
 
 
-def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
+def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     """Per-kernel roofline entries for the MLP kernels of the TIMED training step (fine pass B x (S+N) points and coarse
     pass B x S points): HIP-event time of each kernel launched alone on resident buffers, algorithmic FLOPs and HBM bytes
-    (DESIGN.md §6), fractions of the 2.5 PFLOP/s dense bf16 MFMA peak and of the 8 TB/s HBM peak."""
+    (DESIGN.md §6), fractions of the dense MFMA peak of the kernel's arithmetic and of the 8 TB/s HBM peak.
+    merged: the step runs ONE weight-gradient launch and ONE reduce launch for both models (the fused step at N = 1)."""
     from nerf_pl_amd import _lib, ops
     lib = _lib.load()
     code = ops.mlp_dtype_code(dtype)
@@ -260,7 +264,21 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
     with torch.no_grad():
         z = ops.sample_coarse_z(rays, S, False, 0.0)
         zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
-    for tag, model, zz in (("fine", models[1], zf), ("coarse", models[0], z)):
+
+    def entry(name, tag, P, fn, flops, nbytes, what, key_name=None):
+        avg, mn = event_time(fn, 12, graph=True)
+        tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
+        # the dW GEMM of bf16_f8 runs on the MX-scaled fp8 MFMA: priced against ITS dense peak
+        peak = PEAK_TFLOPS_FP8 if (dtype == "bf16_f8" and name.startswith("mlp_bwd_dw")) else PEAK_TFLOPS[dtype]
+        fm, fh = tf / peak, gbs / PEAK_HBM_GBS
+        key = "%s|%s|%d" % (key_name or name, dtype, P)
+        out.append({"kernel": "%s<%s> %s, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
+                    "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
+                    "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_peak_tflops": peak, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                    "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
+
+    keep, entries, dw_b, P_all = [], [], 0, 0
+    for tag, model, zz in (("fine pass", models[1], zf), ("coarse pass", models[0], z)):
         P = zz.numel()
         pk = model.packed_weights(dtype)
         pb = model.packed_weights_bwd(dtype)
@@ -273,28 +291,33 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db):
         gate_b = (P + 31) // 32 * 9 * 1024
         # split-K partials the reduce kernel reads: per split 592 used (out-tile, x-tile) blocks of 4 KiB over the 12 jobs
         ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 12 * 592 * 4096
-        rows = [
-            ("mlp_fwd_kernel<save>", lambda: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
-             FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point"),
-            ("mlp_bwd_chain_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
-             FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read"),
-            ("mlp_bwd_dw_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=2, workspace=ws),
-             FLOP_PER_POINT_DW * P, (act_b - gate_b) + dy_b, "every saved activation and dY slab read once"),
-            ("mlp_bwd_reduce_kernel", lambda: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=4, workspace=ws),
-             0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written"),
-        ]
-        for name, fn, flops, nbytes, what in rows:
-            avg, mn = event_time(fn, 12, graph=True)
-            tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
-            # the dW GEMM of bf16_f8 runs on the MX-scaled fp8 MFMA: priced against ITS dense peak
-            peak = PEAK_TFLOPS_FP8 if (dtype == "bf16_f8" and name == "mlp_bwd_dw_kernel") else PEAK_TFLOPS[dtype]
-            fm, fh = tf / peak, gbs / PEAK_HBM_GBS
-            key = "%s|%s|%d" % (name, dtype, P)
-            out.append({"kernel": "%s<%s> %s pass, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
-                        "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
-                        "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_peak_tflops": peak, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
-                        "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
-        del acts, raw, g_out, ws
+        entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
+              FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
+        entry("mlp_bwd_chain_kernel", tag, P,
+              lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
+              FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read")
+        if not merged:
+            entry("mlp_bwd_dw_kernel", tag, P,
+                  lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=2, workspace=ws),
+                  FLOP_PER_POINT_DW * P, (act_b - gate_b) + dy_b, "every saved activation and dY slab read once")
+            entry("mlp_bwd_reduce_kernel", tag, P,
+                  lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=4, workspace=ws),
+                  0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written")
+        entries.append((g_out, raw, pb, acts))
+        keep.append((acts, raw, g_out, ws))
+        dw_b += (act_b - gate_b) + dy_b
+        P_all += P
+    if merged:
+        wsm = {}
+        ops.mlp_bwd_multi(entries, dtype, workspace=wsm)            # (chains included: fills the dY slabs the dW launch reads)
+        n_arr = (__import__("ctypes").c_int64 * 2)(*[e[1].numel() // 4 for e in entries])
+        n_slabs = int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, 2, code)) // (4 * (8 * 10 * 64 * 16 + 8 * 64))
+        ws_b = n_slabs * 592 * 4096 // 12        # average used blocks per partial slab (592 of a model's 12 jobs together)
+        entry("mlp_bwd_dw_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=2, workspace=wsm),
+              FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>")
+        entry("mlp_bwd_reduce_kernel", "both models in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=4, workspace=wsm),
+              0, ws_b + 4 * 595844 * 4, "split-K partial slabs read, 48 gradient tensors written", key_name="mlp_bwd_reduce_kernel<merged>")
+    del keep, entries
     return out
 
 
@@ -355,6 +378,9 @@ def main():
             m.mlp_dtype = dtype
         system = system.to(dev)
         (opt,), _ = system.configure_optimizers()
+        system.fused_train_step = not a.modular_step
+        # one rank: no all-reduce sits between the gradients and the update, so the reduce kernel applies Adam in place
+        system.fuse_adam = (dist is None) and not a.no_fuse_adam and not a.modular_step
         return system, opt
 
     system, opt = build_system(a.dtype)
@@ -508,7 +534,7 @@ def main():
                                       "source": "profiles/r02_probe_mfma_rate.txt"}
         if a.mode == "train":
             # ---- the kernels the TIMED step runs, one entry each; `roofline` = the one that takes the most time ----
-            table = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db)
+            table = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db, merged=(system.fused_train_step and grad_sync is None))
             dom = max(table, key=lambda r: r["avg_launch_us"])
             roof = {"bound": dom["bound"], "kernel": dom["kernel"],
                     "achieved": dom["gbs"] if dom["bound"] == "hbm" else dom["tflops"],
@@ -562,6 +588,10 @@ def main():
                                                                          and state["graphed"].graph is not None)
                                  else "hipGraph replay per 32768-ray chunk" if a.mode == "eval" else "eager"),
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if dist is not None and a.mode == "train" else ""),
+                       "step_form": (None if a.mode != "train" else
+                                     "modular autograd graph (render_rays -> MSELoss), separate Adam launch" if a.modular_step else
+                                     "fused node: composite+loss+composite-backward per pass, one pack / dW / reduce launch for both models"
+                                     + (", Adam applied inside the reduce kernel" if system.fuse_adam else ", separate Adam launch")),
                        "rccl_nranks": rccl_nranks,
                        "grad_sync": (None if (grad_sync is None or a.mode != "train") else
                                      ("one hipGraph, all-reduces issued from the grad-ready hooks inside it"

@@ -190,13 +190,14 @@ class GraphedTrainStep:
     time.  The first `warmup` calls run eagerly on the real batches (they are ordinary training steps), the next call
     captures and then replays.  A learning-rate change (scheduler) triggers a re-capture.
 
-    With a `grad_sync` (N > 1 ranks) the step is captured as TWO graphs — [forward + backward] and [optimizer] — with
-    the RCCL all-reduce of the two flat gradient buffers issued eagerly in between (two collective calls per step;
-    `sync_in_graph=True` captures them inside a single graph instead, which RCCL supports but which is only
-    exercised at world size 1 here).
+    With a `grad_sync` (N > 1 ranks) the step is by default ONE graph too: the all-reduces the grad-ready hooks issue are
+    captured inside it (RCCL supports capture) and overlap the rest of the backward on replay.  `sync_in_graph=False`
+    captures TWO graphs — [forward + backward] and [optimizer] — with the all-reduce of the two flat gradient buffers issued
+    eagerly in between.  World-1 A/B on one MI355X (RCCL communicator of one rank, profiles/README.md round 3): one graph
+    0.957 ms, two graphs 0.982 ms, no communicator 0.908 ms per step.
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
-    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=False, backend=None, batch_source=None):
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=True, backend=None, batch_source=None):
         self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
         # `batch_source`: a callable returning the next {'rays', 'rgbs'} batch from device-resident data (RayStore.sample with
         # the default generator).  It is then called INSIDE the step, i.e. captured into the graph: every replay draws a fresh

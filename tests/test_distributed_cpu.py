@@ -85,7 +85,7 @@ def _graphed_step_host_logic(rank, world):
     opt = torch.optim.SGD(sysm.parameters(), lr=0.1)
     sync = parallel.GradSync(sysm.models)
     be = _RecordingBackend()
-    stepper = GraphedTrainStep(sysm, opt, grad_sync=sync, warmup=2, backend=be)
+    stepper = GraphedTrainStep(sysm, opt, grad_sync=sync, warmup=2, backend=be, sync_in_graph=False)    # the two-graph form
     for b in batches[:5]:
         stepper(b)
     ok = be.captures == 2 and stepper.graph is not None and stepper.graph_opt is not None      # two graphs
@@ -114,7 +114,20 @@ def _graphed_step_host_logic(rank, world):
             (ref.training_step(allb[r][i], i)["loss"] / world).backward()
         ropt.step()
     rflat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
-    return bool(ok and torch.allclose(flat, rflat, rtol=1e-5, atol=1e-6))
+    ok = bool(ok and torch.allclose(flat, rflat, rtol=1e-5, atol=1e-6))
+    # the DEFAULT N > 1 form: ONE graph with the collectives inside (issued by sync() during the captured step) — same replicas
+    sys1 = _TinySystem()
+    opt1 = torch.optim.SGD(sys1.parameters(), lr=0.1)
+    be1 = _RecordingBackend()
+    step1 = GraphedTrainStep(sys1, opt1, grad_sync=parallel.GradSync(sys1.models), warmup=2, backend=be1)
+    for i, b in enumerate(batches):
+        if i == 5:
+            for grp in opt1.param_groups:
+                grp["lr"] = 0.05
+        step1(b)
+    flat1 = torch.cat([p.detach().reshape(-1) for p in sys1.parameters()])
+    ok = ok and be1.captures == 2 and step1.graph_opt is None and step1.graph.replays == 2        # one graph per capture
+    return bool(ok and torch.allclose(flat1, rflat, rtol=1e-5, atol=1e-6))
 
 
 def _worker(rank, world, port, n_rays, q):
