@@ -228,7 +228,7 @@ def event_time(fn, reps, warm=3, graph=False):
     if graph:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(reps):
                 fn()
         g.replay()

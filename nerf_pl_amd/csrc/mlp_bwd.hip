@@ -1,5 +1,5 @@
 // K2b: backward of the fused NeRF MLP (autograd mirror of reference models/nerf.py:100-124 as driven by
-// train.py:103-117 `loss.backward()`).  Two hand-written phases:
+// train.py:103-117 `loss.backward()`).  Two hand-written phases (A lives in mlp_bwd_chain.hip, B and the C ABI here):
 //
 //  A  mlp_bwd_chain  — per 32-point wave tile, the same register-resident chain as the forward, run in
 //     reverse with W^T streamed through the LDS ring:  g_h(l-1) = W_l^T g_a(l),  g_a = g_h * relu'(h)
@@ -19,6 +19,7 @@
 #include "mlp_layout.h"
 #include "f8_store.h"
 #include "adam_math.h"
+#include "mlp_bwd_chain.h"
 
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2  // cache-policy bits of the dY stores: 2 = nt (-7 %; whole training step 1.65 -> 1.51 ms)
@@ -37,34 +38,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-template <int PREC> struct BwdTraits;
-template <> struct BwdTraits<NERFHIP_BF16> {
-    using Slab = bf16x8;
-    static constexpr int NW = 8, WPS = 2;
-};
-template <> struct BwdTraits<NERFHIP_F32> {
-    using Slab = f32x8;
-    static constexpr int NW = 4, WPS = 1;
-};
-
-__device__ __forceinline__ void mk_slab(bf16x8& s, const float (&v)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = (__bf16)v[j];
-}
-__device__ __forceinline__ void mk_slab(f32x8& s, const float (&v)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = v[j];
-}
-__device__ __forceinline__ float slab_absmax8(const bf16x8& s) {
-    float m = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)s[j]));
-    return m;
-}
-__device__ __forceinline__ float slab_absmax8(const f32x8& s) { return 0.0f; }   // (fp8 storage is bf16-only; keeps templates uniform)
-__device__ __forceinline__ float slab_get(const bf16x8& s, int j) { return (float)s[j]; }
-__device__ __forceinline__ float slab_get(const f32x8& s, int j) { return s[j]; }
 
 __device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -86,288 +59,6 @@ __device__ __forceinline__ void glds16b_nt(const void* gsrc, unsigned lds_dst) {
 #else
     glds16b(gsrc, lds_dst);
 #endif
-}
-
-// ================================================================================================
-// Phase A: backward chain
-// ================================================================================================
-template <int PREC>
-struct BwdStream {
-    static constexpr int NW = BwdTraits<PREC>::NW;
-    static constexpr int LPW = kChunkPieces / NW;
-    static constexpr int NCH = bwd_chunks(PREC);
-    const uint8_t* gsrc;
-    unsigned lds_base;
-    int wave;
-    int pending;   // stores issued since the last boundary (constant-folded; see mlp_fwd.hip)
-    int pending_prev;
-
-    __device__ __forceinline__ void issue_chunk(int c) const {
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int piece = wave + i * NW;
-            glds16b(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
-                    lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
-        }
-    }
-    __device__ __forceinline__ void boundary(int c) {
-        // chunk c's DMAs were issued at boundary c-2: younger than them are the stores of the interval before the previous
-        // boundary (pending_prev), chunk c+1's DMAs and the stores since the previous boundary => stores get two chunk
-        // intervals to retire before a boundary waits for them
-        const int n = (c + 1 < NCH ? LPW : 0) + pending + (NERFHIP_STORE_SLACK ? pending_prev : 0);
-        pending_prev = pending;
-        pending = 0;
-#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-        switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {
-            NH_WB(0) NH_WB(1) NH_WB(2) NH_WB(3) NH_WB(4) NH_WB(5) NH_WB(6) NH_WB(7) NH_WB(8)
-            NH_WB(12) NH_WB(16) NH_WB(20) NH_WB(24) NH_WB(28) NH_WB(32) NH_WB(36) NH_WB(40) NH_WB(44) NH_WB(48)
-            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-        }
-#undef NH_WB
-        if (c + 2 < NCH) issue_chunk(c + 2);
-    }
-};
-
-template <typename Slab>
-__device__ __forceinline__ Slab load_slab(__amdgpu_buffer_rsrc_t rsrc, int sec, int lane) {
-    Slab s;
-    u32x4* dst = reinterpret_cast<u32x4*>(&s);
-    const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
-    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16 * q, soff, 0);
-    return s;
-}
-template <int PREC, typename Slab>
-__device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_rsrc_t rsrc, int sec, const Slab& s, int lane) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(&s);
-    const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
-    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-        // soffset must stay 0 (offset folded into VOFFSET): gfx950 store-data hazard, see mlp_fwd.hip save_slabs
-        __builtin_amdgcn_raw_buffer_store_b128(src[q], rsrc, voff + soff + 16 * q, 0, NERFHIP_STORE_AUX);
-        st.pending += 1;
-    }
-}
-
-// dY pair store / block scale in the configured 8-bit format (f8_store.h: e5m2 by default, see NERFHIP_F8_DY_E5M2)
-__device__ __forceinline__ void save_dy_pair(int& pending, uint8_t* dy_tile, int pair, const bf16x8& s0, const bf16x8& s1, int sb, int lane) {
-#if NERFHIP_F8_DY_E5M2
-    save_pair_bf8(pending, dy_tile, pair, s0, s1, sb, lane);
-#else
-    save_pair_f8(pending, dy_tile, pair, s0, s1, sb, lane);
-#endif
-}
-__device__ __forceinline__ void save_dy_pair(int&, uint8_t*, int, const f32x8&, const f32x8&, int, int) {}    // (never used: fp8 storage is bf16-only)
-__device__ __forceinline__ int dy_block_scale(float lane_max) {
-#if NERFHIP_F8_DY_E5M2
-    return bf8_block_scale(lane_max);
-#else
-    return f8_block_scale(lane_max);
-#endif
-}
-
-// sign-extended one-bit field of a gate word: 0 or ~0.  (As inline asm: written with the builtin or plain C, hipcc turns the
-// constant-position extract + AND into v_and + v_cmp + v_cndmask, three VALU per value instead of two.)
-template <int BIT>
-__device__ __forceinline__ unsigned gate_mask(unsigned word) {
-    unsigned m;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
-    return m;
-}
-
-template <int B, int E, typename F>
-__device__ __forceinline__ void bwd_static_for(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        bwd_static_for<B + 1, E>(f);
-    }
-}
-
-// ---- one backward layer, OUTPUT-TILE-MAJOR: for each 32-row tile t of g_h(l-1) = W_l^T g_a(l):
-// 16-17 chained MFMAs over the input slabs, then the tile's epilogue — ReLU gate, bf16 pack into slabs 2t, 2t+1 of the OTHER
-// slab set (a layer reads one set while its tiles fill the other), stores — which overlaps the next tile's MFMAs (other
-// accumulator) instead of forming one ~420-instruction VALU block per layer during which the matrix pipe idles.
-// fp8 storage: like the forward, a layer stores its INPUT section (`gin`, live for the whole layer; `in_pairs` slab pairs
-// spread over the tiles, under the scale byte `in_sb` computed by ONE reduction at the end of the layer that produced it)
-// and returns the scale byte of its own output.
-template <int PREC, int L, int NT, int NKS, bool MASK, bool F8, int IN_PAIRS, typename Slab>
-__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char* smem_lane, const Slab (&gin)[NKS], Slab* out,
-                                                __amdgpu_buffer_rsrc_t acts, int gate_off, int mask_piece,
-                                                __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int in_sec,
-                                                int in_sb, int lane) {
-    constexpr int G0 = bwd_layer_start(L, PREC);
-    constexpr int PPF = ppf(PREC);
-    static_assert(kBwdLayers[L].nt == NT && kBwdLayers[L].nks == NKS, "bwd layer shape mismatch");
-    auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
-    u32x4 gates = {0u, 0u, 0u, 0u};
-    if (MASK)
-        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
-    float mx = 0.0f;
-    f32x16 acc2[2];
-    // compile-time loop over the tiles: guarantees static register indexing of the slab arrays (a `#pragma unroll` loop of
-    // this size is not always fully unrolled, and one runtime index sends a whole 17-slab array to scratch memory)
-    bwd_static_for<0, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        f32x16& acc = acc2[t & 1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int g = G0 + (t * NKS + ks) * PPF;
-            if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
-            if constexpr (PREC == NERFHIP_BF16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gin[ks], acc, 0, 0, 0);
-            } else {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
-                if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], gin[ks][j], acc, 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], gin[ks][4 + j], acc, 0, 0, 0);
-            }
-        }
-        if constexpr (F8 && PREC == NERFHIP_BF16) {                  // this tile's share of the INPUT section's pairs
-            if constexpr (IN_PAIRS > 0) {
-#pragma unroll
-                for (int q = 0; q < IN_PAIRS; ++q)
-                    if (q >= t * IN_PAIRS / NT && q < (t + 1) * IN_PAIRS / NT)        // folds: t is an unrolled constant
-                        save_dy_pair(st.pending, dy_tile, in_sec / 2 + q, gin[2 * q], gin[2 * q + 1], in_sb, lane);
-            }
-        }
-        // ---- epilogue of tile t: g wrt pre-activation = g * relu'(pre-act) (gate bit: mlp_layout.h gate_word / gate_bit) ----
-        float v[16];
-        bwd_static_for<0, 16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;           // slab 2t + (r >> 3), slot r & 7
-            constexpr int idx = 8 * (2 * t) + r;
-            const float gv = acc[r];
-            if constexpr (MASK) v[r] = __uint_as_float(__float_as_uint(gv) & gate_mask<gate_bit(idx)>(gates[gate_word(idx)]));
-            else v[r] = gv;
-            if (F8) mx = fmaxf(mx, fabsf(v[r]));
-        });
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            float v8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v8[j] = v[8 * sl + j];
-            mk_slab(out[2 * t + sl], v8);
-            if constexpr (!F8) store_slab(st, dys, dy_sec + 2 * t + sl, out[2 * t + sl], lane);
-        }
-    });
-    if constexpr (F8 && PREC == NERFHIP_BF16) {
-        const int sb = dy_block_scale(mx);
-        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
-        return sb;
-    }
-    return 127;
-}
-
-template <int PREC, bool F8>
-__global__ __launch_bounds__(BwdTraits<PREC>::NW * 64, BwdTraits<PREC>::WPS)
-void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ g_scale, const float* __restrict__ out,
-                          int64_t n, const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
-                          uint8_t* __restrict__ dys_base) {
-    static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
-    using Slab = typename BwdTraits<PREC>::Slab;
-    constexpr int kActTile = F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC);
-    constexpr int kGateOff = F8 ? f8_act_gate_off() : act_mask_off(PREC);
-    constexpr int kDyTile = F8 ? f8_dy_tile_bytes() : kDySlabs * 64 * (int)sizeof(Slab);
-    constexpr int NW = BwdTraits<PREC>::NW;
-    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * NW + wave;
-    const int64_t p = tile * 32 + (lane & 31);
-    const bool valid = p < n;
-    const int64_t pc = valid ? p : n - 1;
-
-    float4 g = reinterpret_cast<const float4*>(g_out)[pc];
-    const float4 o = reinterpret_cast<const float4*>(out)[pc];
-    if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);               // padded points contribute nothing
-    if (g_scale) {                                                 // upstream d L / d loss as a device scalar (NULL = 1)
-        const float sc = *g_scale;
-        g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
-    }
-
-    __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(acts_base) + (size_t)tile * kActTile, 0, kActTile, 0x00020000);
-    uint8_t* dy_tile = dys_base + (size_t)tile * kDyTile;
-    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(dy_tile, 0, kDyTile, 0x00020000);
-
-
-    BwdStream<PREC> st;
-    st.gsrc = packed_bwd + lane * 16;
-    st.lds_base = (unsigned)(uintptr_t)ring;
-    st.wave = wave;
-    st.pending = 0;
-    st.pending_prev = 0;
-    st.issue_chunk(0);
-    st.issue_chunk(1);
-    const char* smem_lane = ring + lane * 16;
-
-    // d sigmoid: g_a_rgb = g_rgb * rgb * (1 - rgb)      (nerf.py:79-81, 120);  sigma is linear (nerf.py:112)
-    float v[8];
-    Slab zero_slab;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-    mk_slab(zero_slab, v);
-    Slab g_rgb, g_sig;
-    {
-        const float ga[3] = {g.x * o.x * (1.0f - o.x), g.y * o.y * (1.0f - o.y), g.z * o.z * (1.0f - o.z)};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (h == 0 && j < 3) ? ga[j < 3 ? j : 0] : 0.0f;
-        mk_slab(g_rgb, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (h == 0 && j == 0) ? g.w : 0.0f;
-        mk_slab(g_sig, v);
-    }
-    if constexpr (F8) {
-        if constexpr (PREC == NERFHIP_BF16) {
-#if NERFHIP_F8_DY_E5M2
-            const int sb_rgb = bf8_block_scale(slab_absmax8(g_rgb)), sb_sig = bf8_block_scale(slab_absmax8(g_sig));
-            save_pair_bf8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, sb_rgb, lane);
-            save_pair_bf8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, sb_sig, lane);
-#else
-            const int sb_rgb = f8_block_scale(slab_absmax8(g_rgb)), sb_sig = f8_block_scale(slab_absmax8(g_sig));
-            save_pair_f8(st.pending, dy_tile, kDyRgb / 2, g_rgb, zero_slab, sb_rgb, lane);
-            save_pair_f8(st.pending, dy_tile, kDySigma / 2, g_sig, zero_slab, sb_sig, lane);
-#endif
-            save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(kDyRgb), sb_rgb, lane);
-            save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(kDySigma), sb_sig, lane);
-        }
-    } else {
-        store_slab(st, dys, kDyRgb, g_rgb, lane);
-        store_slab(st, dys, kDyRgb + 1, zero_slab, lane);
-        store_slab(st, dys, kDySigma, g_sig, lane);
-        store_slab(st, dys, kDySigma + 1, zero_slab, lane);
-    }
-
-    // scale bytes of the sections produced so far (F8); rgb / sigma pairs were stored above
-    Slab gd[8];
-    Slab ga[17], gb[17];
-    // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)  -> dY_dir in gd
-    Slab g_in0[1] = {g_rgb};
-    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, smem_lane, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
-                                                          -1, 127, lane);
-    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga   (F8: stores its input dY_dir)
-    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, smem_lane, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, kDyDir, sb, lane);
-    ga[16] = g_sig;
-    // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (F8: stores dY_feat)
-    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, smem_lane, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
-                                                       kDyFeat, sb, lane);
-#define NH_BWD(L, IN, OUT)                                                                                                  \
-    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, smem_lane, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
-                                                       mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), dy_h(11 - L), sb, lane);
-    NH_BWD(3, gb, ga) NH_BWD(4, ga, gb) NH_BWD(5, gb, ga) NH_BWD(6, ga, gb) NH_BWD(7, gb, ga) NH_BWD(8, ga, gb) NH_BWD(9, gb, ga)
-#undef NH_BWD
-    if constexpr (F8 && PREC == NERFHIP_BF16) {              // the last section (dY_1) has no consuming layer: flush it
-#pragma unroll
-        for (int q = 0; q < 8; ++q) save_dy_pair(st.pending, dy_tile, dy_h(1) / 2 + q, ga[2 * q], ga[2 * q + 1], sb, lane);
-    }
 }
 
 // ================================================================================================
@@ -961,21 +652,6 @@ extern "C" size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_h
     return (size_t)dw_plan(n_points_host, n_models, dtype, nullptr) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
 }
 
-// chain launch of one model
-static void launch_chain(const float* g_out, const float* g_scale, const float* out, int64_t n, const void* packed_bwd,
-                         const void* acts, void* dys, int dtype, hipStream_t s) {
-    const int64_t tiles = act_tiles(n, dtype);
-    if (dtype == NERFHIP_BF16_F8)
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, g_scale,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-    else if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out,
-                           g_scale, out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-    else
-        hipLaunchKernelGGL((nerfhip::mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, g_scale,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
-}
-
 extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const float* const* out_host,
                                      const int64_t* n_host, const void* const* packed_bwd_host, const void* const* acts_host,
                                      void* const* dys_host, void* dw_workspace, float* const* grad_w_host,
@@ -1019,7 +695,8 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
     const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), (unsigned)jt.njobs);
     const bool do_chain = phases & 1, do_dw = phases & 2, do_reduce = phases & 4;
     if (do_chain)
-        for (int m = 0; m < n_models; ++m) launch_chain(g_out_host[m], g_scale, out_host[m], n_host[m], packed_bwd_host[m], acts_host[m], dys_host[m], dtype, s);
+        for (int m = 0; m < n_models; ++m) nerfhip::launch_bwd_chain(g_out_host[m], g_scale, out_host[m], n_host[m], packed_bwd_host[m], acts_host[m], dys_host[m], dtype,
+                                                                   act_tiles(n_host[m], dtype), s);
     if (do_dw) {
         if (dtype == NERFHIP_BF16_F8)
             hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, (float*)dw_workspace);

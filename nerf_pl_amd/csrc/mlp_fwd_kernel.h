@@ -29,6 +29,9 @@
 #ifndef NERFHIP_EXP
 #define NERFHIP_EXP 0
 #endif
+#ifndef NERFHIP_DMA_SADDR
+#define NERFHIP_DMA_SADDR 1     // weight-stream DMAs address as SGPR base + one constant per-lane VGPR offset (no per-piece VALU address)
+#endif
 #ifndef NERFHIP_PF2
 #define NERFHIP_PF2 2      // prefetch depth of the 2-waves-per-SIMD (256-register) bf16 kernels
 #endif
@@ -78,11 +81,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
+// the same with the source as wave-uniform base (SGPR pair) + per-lane byte offset `voff`
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
 template <int PREC, int NCH, bool COUNT_STORES = false>
 struct WeightStream {
     static constexpr int NW = KCfg<PREC, COUNT_STORES>::NW;    // COUNT_STORES == SAVE variant
     static constexpr int LPW = kChunkPieces / NW;   // DMA instructions per wave per chunk
-    const uint8_t* gsrc;     // packed + lane*16
+    const uint8_t* gsrc;     // packed + lane*16 | NERFHIP_DMA_SADDR: packed (wave-uniform)
+    unsigned voff;           // NERFHIP_DMA_SADDR: lane*16
     unsigned lds_base;       // LDS byte address of the ring
     int wave;                // wave index in the workgroup (SGPR)
     int pending;             // vector-memory STORE instructions issued since the last boundary (SAVE variant).
@@ -91,8 +105,13 @@ struct WeightStream {
 
     __device__ __forceinline__ void issue_piece(int c, int k) const {      // k-th of this wave's LPW pieces of chunk c
         const int piece = wave + k * NW;
+#if NERFHIP_DMA_SADDR
+        glds16_s(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes, voff,
+                 lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
+#else
         glds16(gsrc + ((size_t)c * kChunkPieces + piece) * kPieceBytes,
                lds_base + (unsigned)((c % kSlots) * kChunkBytes + piece * kPieceBytes));
+#endif
     }
     __device__ __forceinline__ void issue_chunk(int c) const {
 #pragma unroll
@@ -573,7 +592,12 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     }
 
     WeightStream<PREC, NCH, SAVE> st;
+#if NERFHIP_DMA_SADDR
+    st.gsrc = packed;
+#else
     st.gsrc = packed + lane * 16;
+#endif
+    st.voff = (unsigned)lane * 16u;
     st.lds_base = (unsigned)(uintptr_t)ring;
     st.wave = wave;
     st.pending = 0;
@@ -588,9 +612,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
         constexpr int NLY = SIGMA_ONLY ? kSigmaLayer + 1 : kNumLayers;
         static_for<0, NLY>([&](auto lc) {
             constexpr int Lb = decltype(lc)::value;
-            if (wave == Lb % NW)
+            if (wave == Lb % NW) {
+#if NERFHIP_DMA_SADDR
+                glds16_s(st.gsrc + (size_t)(bias_block_start(PREC) + Lb) * kPieceBytes, st.voff,
+                         (unsigned)(uintptr_t)bias_area + (unsigned)(Lb * kPieceBytes));
+#else
                 glds16(st.gsrc + (size_t)(bias_block_start(PREC) + Lb) * kPieceBytes,
                        (unsigned)(uintptr_t)bias_area + (unsigned)(Lb * kPieceBytes));
+#endif
+            }
         });
     }
     st.issue_chunk(0);

@@ -93,7 +93,8 @@ class GraphRenderer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # (thread_local: an RCCL watchdog thread polling events elsewhere in the process must not abort the capture)
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = _render_test_time(self.models, self.rays, S, N, disp, wb)
 
     @torch.no_grad()

@@ -36,12 +36,14 @@ class _MLPRays(torch.autograd.Function):
         packed, packed_bwd = model.packed_weights_train(dtype)
         out = ops.mlp_fwd_rays(rays, z, packed, False, dtype, save=acts)
         ctx.model, ctx.dtype, ctx.acts, ctx.packed_bwd = model, dtype, acts, packed_bwd
+        ctx.serial = model._packed_serial
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         (out,) = ctx.saved_tensors
+        ctx.model.check_pack_serial(ctx.serial)
         grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, ctx.packed_bwd)
         ctx.acts = ctx.packed_bwd = None
         return (None, None, None) + tuple(grads)
@@ -53,16 +55,22 @@ class _MLPEmbedded(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         dtype = model.mlp_dtype
+        if dtype == "bf16_f8" and ctx.needs_input_grad[1]:
+            # d/dx needs dY of three layers at full bf16 precision (nerfhip_mlp_dx_embedded); the 8-bit mode keeps dY only as
+            # e5m2 copies for the dW GEMM.  Same bf16 MFMA forward and chain: this call simply saves its tensors in bf16.
+            dtype = "bf16"
         acts = ops.alloc_acts(x.shape[0], dtype, x.device)
         packed, packed_bwd = model.packed_weights_train(dtype)
         out = ops.mlp_fwd_embedded(x, packed, False, dtype, save=acts)
         ctx.model, ctx.dtype, ctx.acts, ctx.packed_bwd = model, dtype, acts, packed_bwd
+        ctx.serial = model._packed_serial
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         (out,) = ctx.saved_tensors
+        ctx.model.check_pack_serial(ctx.serial)
         ws = {} if ctx.needs_input_grad[1] else None
         grads = _param_grads(ctx.model, out, ctx.acts, ctx.dtype, g_out, ctx.packed_bwd, workspace=ws)
         ctx.acts = ctx.packed_bwd = None

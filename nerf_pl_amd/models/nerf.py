@@ -135,7 +135,10 @@ class NeRF(nn.Module):
 
     def packed_weights_train(self, dtype=None):
         """(forward image, W^T image) of the current parameters in ONE launch: a training forward packs both, its backward
-        (same weights: autograd forbids changing them in between) reuses the second."""
+        reuses the second.  The images live in ONE buffer per model: a later training forward of the same model re-packs them.
+        That is harmless while the weights are unchanged (identical images) and WRONG if an optimizer stepped in between —
+        PyTorch raises for its own saved tensors in that situation; here it is detected only for optimizers that announce their
+        updates (FlatAdam bumps `_weights_serial`; `check_pack_serial` in the backward), not for foreign in-place updates."""
         if not self.is_default_arch():
             raise NotImplementedError("the fused HIP MLP implements the reference's default architecture "
                                       "(D=8, W=256, skips=[4], 63/27 inputs) only")
@@ -146,7 +149,14 @@ class NeRF(nn.Module):
             buf = self._packed_cache[dtype] = torch.empty(ops.packed_bytes(dtype), device=dev, dtype=torch.uint8)
         bwd = self._bwd_buffer(dtype, dev)
         ops.pack_weights_train_raw(wp, bp, buf, bwd, dtype)
+        self._packed_serial = getattr(self, "_weights_serial", 0)
         return buf, bwd
+
+    def check_pack_serial(self, serial):
+        """backward side of packed_weights_train: the W^T image must still be the one packed from the weights of `serial`"""
+        if getattr(self, "_packed_serial", 0) != serial:
+            raise RuntimeError("the W^T image this backward needs was re-packed from UPDATED weights by a later training forward of "
+                               "the same model (an optimizer stepped between this graph's forward and its backward)")
 
     def forward(self, x, sigma_only=False):
         """x: (B, 63+27) embedded position+direction, or (B, 63) when sigma_only.

@@ -67,6 +67,7 @@ class _TrainRender(torch.autograd.Function):
         ctx.models = [models[1], models[0]] if N > 0 else [models[0]]
         ctx.entries, ctx.dtype, ctx.adam = entries, dtype, adam
         ctx.n_params = [len(m.flat_params()) for m in models]
+        ctx.serials = [m._packed_serial for m in ctx.models]
         ctx.mark_non_differentiable(out3, *outs)
         ctx.set_materialize_grads(False)
         return (out3[0], out3) + tuple(outs)
@@ -81,6 +82,8 @@ class _TrainRender(torch.autograd.Function):
         # caller passed to backward()
         g_scale = None if ops.is_unit_seed(g_loss) else g_loss.reshape(1).float().contiguous()
         models, dtype = ctx.models, ctx.dtype
+        for m, serial in zip(models, ctx.serials):
+            m.check_pack_serial(serial)
         hooked = any(getattr(m, "_grad_ready_hook", None) is not None for m in models)
         if hooked:
             # N > 1 ranks: per model chain -> dW -> reduce -> grad-ready hook, so that the fine model's all-reduce travels

@@ -464,8 +464,8 @@ def mlp_dx_embedded(dys, n, w_xyz1, w_xyz5, w_dir, dtype):
     """dL/dx (n, 90) of NeRF.forward on pre-embedded inputs from the dY slabs of the preceding mlp_bwd call."""
     code = mlp_dtype_code(dtype)
     if code == BF16_F8:
-        raise NotImplementedError("gradient w.r.t. pre-embedded NeRF inputs needs mlp_dtype 'bf16' or 'fp32' "
-                                  "('bf16_f8' keeps dY only as e5m2)")
+        raise NotImplementedError("nerfhip_mlp_dx_embedded reads bf16 / fp32 dY slabs ('bf16_f8' keeps dY only as e5m2: NeRF.forward "
+                                  "saves in bf16 for calls whose input requires grad, models/mlp_autograd.py)")
     require_gpu(w_xyz1, w_xyz5, w_dir)
     gx = torch.empty(n, 90, device=dys.device, dtype=torch.float32)
     check(_lib.load().nerfhip_mlp_dx_embedded(ptr(dys), n, ptr(_c(w_xyz1.detach())), ptr(_c(w_xyz5.detach())), ptr(_c(w_dir.detach())),
@@ -494,6 +494,8 @@ def pack_models_train(models, dtype):
     with torch.cuda.device(bufs[0][0].device):
         check(_lib.load().nerfhip_mlp_pack_weights_train_multi(W, Bv, P, Pb, n, mlp_dtype_code(dtype), stream_ptr()),
               "nerfhip_mlp_pack_weights_train_multi")
+    for m in models:
+        m._packed_serial = getattr(m, "_weights_serial", 0)
     return bufs
 
 

@@ -39,6 +39,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.dev_state = torch.zeros(2, device=dev, dtype=torch.float32)
         self._tables = None
         self._applied = None          # ids of the models whose update the last backward already applied (fused reduce + Adam)
+        self._stepped = None          # indices of the models the first step updated (must stay the same: one shared step counter)
 
     # ---------------------------------------------------------------------------------------------- flat storage
     @staticmethod
@@ -122,6 +123,12 @@ class FlatAdam(torch.optim.Optimizer):
 
     def applied_in_backward(self, models):
         self._applied = {id(m) for m in models}
+        self._bump_serial([j for j, mm in enumerate(self.models) if any(mm is m for m in models)])
+
+    def _bump_serial(self, idx):
+        """the weights of these models changed: packed weight images made before this point are stale (models/nerf.py)"""
+        for i in idx:
+            self.models[i]._weights_serial = getattr(self.models[i], "_weights_serial", 0) + 1
 
     # ---------------------------------------------------------------------------------------------- the update
     @torch.no_grad()
@@ -135,12 +142,23 @@ class FlatAdam(torch.optim.Optimizer):
             done, self._applied = self._applied, None
             if done != {id(m) for m in self.models}:
                 raise _lib.NerfHipError("FlatAdam: the fused backward updated only some of the optimizer's models")
+            if self._stepped is None:
+                self._stepped = tuple(range(len(self.models)))
             return loss
         self._check_alias()
         self._gather_grads()
         idx = [i for i, f in enumerate(self.flats) if f.grad is not None]
         if not idx:
             return loss
+        # ONE device-resident step counter serves every model (torch.optim.Adam keeps one per parameter): that is only the same
+        # thing while the same models are stepped every time — a model that sat out a step would get the others' bias correction
+        if self._stepped is None:
+            self._stepped = tuple(idx)
+        elif self._stepped != tuple(idx):
+            raise _lib.NerfHipError("FlatAdam: the set of models with gradients changed between steps (%s -> %s); one shared step "
+                                    "counter cannot represent that — use torch.optim.Adam for partially frozen training"
+                                    % (self._stepped, tuple(idx)))
+        self._bump_serial(idx)
         g = self.param_groups[0]
         n = len(idx)
         arr = ctypes.c_void_p * n

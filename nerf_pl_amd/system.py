@@ -309,6 +309,9 @@ class _HipGraphBackend:
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         kw = {"pool": share_pool_with.pool()} if share_pool_with is not None else {}
-        with torch.cuda.graph(graph, stream=self.stream, **kw):
+        # thread_local: with a process group alive, RCCL's watchdog THREAD polls the events of earlier eager collectives; under
+        # the default (global) capture mode one such hipEventQuery during the capture aborts the process ("operation not
+        # permitted when stream is capturing") — a race that only shows on some runs
+        with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local", **kw):
             out = fn()
         return graph, out

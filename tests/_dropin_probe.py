@@ -86,4 +86,42 @@ m = our_nerf.NeRF()
 train.load_ckpt(m, path, model_name="nerf_coarse")
 report["load_ckpt_roundtrip"] = all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), ck["state_dict"].values()))
 os.remove(path)
+
+# ---- with a GPU present: the reference's OWN training_step (train.py:103-117), forward chunk loop (train.py:49-71), loss
+# (losses.py), optimizer (utils/__init__.py:10-30) and scheduler run a few real steps on top of this package's kernels, plain and
+# under stock torch DistributedDataParallel at world size 1 (what Lightning's DDP wrapper does, train.py:174-175) ----
+report["gpu"] = torch.cuda.is_available()
+if report["gpu"]:
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    system = system.to(dev)
+    (opt,), (sch,) = system.configure_optimizers()                      # the reference's method: sets system.optimizer
+    g = torch.Generator().manual_seed(0)
+    o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(512, 3, generator=g)
+    d = torch.nn.functional.normalize(0.8 * torch.randn(512, 3, generator=g) - o, dim=-1)
+    batch = {"rays": torch.cat([o, d, torch.full((512, 1), 2.0), torch.full((512, 1), 6.0)], 1).to(dev),
+             "rgbs": torch.rand(512, 3, generator=g).to(dev)}
+    losses = []
+    for i in range(5):
+        out = system.training_step(batch, i)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    report["training_step_losses"] = losses
+    report["training_step_keys"] = sorted(out.keys())
+    report["training_step_grads_finite"] = all(bool(torch.isfinite(p.grad).all()) for p in system.parameters() if p.grad is not None)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(system, device_ids=[0])
+        res = ddp(batch["rays"])                                          # -> train.NeRFSystem.forward
+        loss = system.loss(res, batch["rgbs"])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        report["ddp_world1_loss"] = float(loss)
+    finally:
+        dist.destroy_process_group()
 print("DROPIN_REPORT " + json.dumps(report))

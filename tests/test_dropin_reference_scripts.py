@@ -32,3 +32,8 @@ def test_reference_train_and_eval_run_on_this_package():
     assert rep["eval_batched_inference_args"] == ["models", "embeddings", "rays", "N_samples", "N_importance", "use_disp", "chunk",
                                                   "white_back"]
     assert rep["loss"] == "MSELoss"
+    if rep.get("gpu"):         # a box with BOTH the reference tree and an MI355X: the reference's own training_step ran on our kernels
+        ls = rep["training_step_losses"]
+        assert rep["training_step_keys"] == ["log", "loss", "progress_bar"] and rep["training_step_grads_finite"]
+        assert all(l == l and l < 10 for l in ls) and min(ls[2:]) < ls[0], ls
+        assert rep["ddp_world1_loss"] == rep["ddp_world1_loss"]

@@ -355,7 +355,7 @@ def test_sigma_only_forward_is_differentiable(dev):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gradient_wrt_preembedded_inputs(dev, dtype):
     """NeRF.forward is differentiable w.r.t. its (pre-embedded) input like the reference module (nerf.py:100-124):
-    nerfhip_mlp_dx_embedded against autograd through the oracle; the fp8-storage mode refuses (its dY is e5m2)."""
+    nerfhip_mlp_dx_embedded against autograd through the oracle; in the fp8-storage mode such a call saves in bf16."""
     n = 700
     g = torch.Generator().manual_seed(5)
     p = O.make_params(21, 3.0, 0.1)
@@ -383,10 +383,17 @@ def test_gradient_wrt_preembedded_inputs(dev, dtype):
     (m(x3, sigma_only=True) * g_out[:, 3:].to(dev)).sum().backward()
     if dtype == "fp32":
         assert (x3.grad.cpu() - x2.grad).abs().max().item() <= 2e-4 * x2.grad.abs().max().item()
-    (m8,), _ = build_models([p], dev, "bf16_f8")
-    x4 = x.clone().to(dev).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        (m8(x4) * g_out.to(dev)).sum().backward()
+    # the 8-bit storage mode: a call whose input requires grad saves its tensors in bf16 (the 8-bit mode keeps dY only as e5m2
+    # copies for the dW GEMM), so d/dx and the parameter gradients of THAT call equal the bf16 mode's bit for bit
+    if dtype == "bf16":
+        res = {}
+        for dt in ("bf16", "bf16_f8"):
+            (mm,), _ = build_models([p], dev, dt)
+            x4 = x.clone().to(dev).requires_grad_(True)
+            (mm(x4) * g_out.to(dev)).sum().backward()
+            res[dt] = (x4.grad.clone(), [q.grad.clone() for q in mm.parameters()])
+        assert torch.equal(res["bf16"][0], res["bf16_f8"][0])
+        assert all(torch.equal(a, b) for a, b in zip(res["bf16"][1], res["bf16_f8"][1]))
 
 
 def test_empty_batch_gradients_are_zero(dev):
@@ -462,6 +469,52 @@ def test_graphed_step_with_rccl_allreduce_world1(dev):
             ls = [stepper(batch)["loss"].item() for _ in range(8)]
             assert stepper.graph is not None and (stepper.graph_opt is None) == in_graph
             assert all(torch.isfinite(torch.tensor(ls))) and min(ls[-3:]) < ls[0], (in_graph, ls)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stock_ddp_world1_on_flat_buffer_grads(dev):
+    """INTEGRATION.md "DDP works as is" (the reference gets DDP from Lightning, train.py:174-175): stock
+    torch.nn.parallel.DistributedDataParallel around NeRFSystem — its autograd hooks, bucket copies and RCCL all-reduce on top
+    of parameter gradients that are views of the flat buffer the dW-reduce kernel wrote.  World size 1: the averaged gradients
+    must equal the plain ones."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from argparse import Namespace
+    from nerf_pl_amd.system import NeRFSystem
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=0.0, noise_std=0.0, chunk=1024 * 32,
+                   loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True, optimizer="adam",
+                   flat_optimizer=False)
+    batch = {"rays": O.make_rays(1, 200, "blender").to(dev), "rgbs": torch.rand(200, 3, generator=torch.Generator().manual_seed(0)).to(dev)}
+
+    def build():
+        system = NeRFSystem(hp)
+        system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
+        for m in system.models:
+            m.mlp_dtype = "fp32"
+        return system.to(dev)
+    plain = build()
+    plain.loss(plain(batch["rays"]), batch["rgbs"]).backward()
+    want = {n: p.grad.clone() for n, p in plain.named_parameters()}
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        system = build()
+        ddp = torch.nn.parallel.DistributedDataParallel(system, device_ids=[dev.index or 0])
+        for _ in range(2):                                   # twice: the second backward accumulates into / rebuilds bucket views
+            system.zero_grad(set_to_none=True)
+            system.loss(ddp(batch["rays"]), batch["rgbs"]).backward()
+        torch.cuda.synchronize()
+        for n, p in system.named_parameters():
+            assert p.grad is not None and torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-9), n
+        opt = torch.optim.Adam(system.parameters(), lr=5e-4)
+        opt.step()
     finally:
         dist.destroy_process_group()
 

@@ -1,0 +1,31 @@
+# A/B of kernel variants (one box, one call): kbench per library build + a correctness subset per build
+mkdir -p gpurun_out/r03d
+OUT=gpurun_out/r03d
+for rep in 1 2; do
+for v in main old saddr xbf8; do
+  if [ $v = main ]; then unset NERFHIP_LIB_PATH; else export NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_$v.so; fi
+  for S in 192 64; do
+    python tools/kbench.py --dtype bf16_f8 --samples $S --reps 20 2>/dev/null | tail -1 | sed "s/^/[$v rep$rep] /" | tee -a $OUT/kbench.txt
+  done
+done
+done
+for v in main old saddr xbf8; do
+  if [ $v = main ]; then unset NERFHIP_LIB_PATH; else export NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_$v.so; fi
+  python -m pytest tests/test_gpu_training.py tests/test_gpu_fused_step.py tests/test_gpu_bf16.py -q -x -k "mlp_backward_embedded or f8_storage or golden or fused_step_equals or gradient_direction or stock_ddp" 2>&1 | tail -3 | sed "s/^/[$v] /" | tee -a $OUT/pytest_variants.txt
+done
+unset NERFHIP_LIB_PATH
+python -m pytest tests/test_bench_contract.py -q -m gpu -s 2>&1 | tail -5 | tee $OUT/pytest_bench_contract.txt
+# the e5m2-X variant is only interesting if its saving forward is faster: then its PSNR licence
+python - <<'PY'
+import re,subprocess,os
+t={}
+for l in open('gpurun_out/r03d/kbench.txt'):
+    m=re.match(r"\[(\w+) rep\d\] .* 1024x192 .*fwd\+save ([\d.]+)",l)
+    if m: t.setdefault(m.group(1),[]).append(float(m.group(2)))
+print({k:min(v) for k,v in t.items()})
+if min(t.get('xbf8',[1e9])) < 0.97*min(t.get('saddr',[0])):
+    env=dict(os.environ, NERFHIP_LIB_PATH=os.getcwd()+'/nerf_pl_amd/variants/libnerfhip_xbf8.so')
+    subprocess.run("timeout 420 python tools/psnr_gate.py --gate --dtypes bf16_f8 --out gpurun_out/r03d/psnr_gate_xbf8.json > gpurun_out/r03d/psnr_gate_xbf8.log 2>&1; grep -E 'mean|stderr' gpurun_out/r03d/psnr_gate_xbf8.log | tail -8", shell=True, env=env)
+else:
+    print("xbf8 not faster: PSNR gate skipped")
+PY
