@@ -186,14 +186,19 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
 // spread over the tiles, under the scale byte `in_sb` computed by ONE reduction at the end of the layer that produced it)
 // and returns the scale byte of its own output.
 template <int PREC, int L, int NT, int NKS, bool MASK, bool F8, int IN_PAIRS, typename Slab>
-__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char* smem_lane, const Slab (&gin)[NKS], Slab* out,
+__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsigned lds_lo, const unsigned lds_hi, const Slab (&gin)[NKS], Slab* out,
                                                 __amdgpu_buffer_rsrc_t acts, int gate_off, int mask_piece,
-                                                __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int in_sec,
+                                                __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int dy_scale_idx, int in_sec,
                                                 int in_sb, int lane) {
     constexpr int G0 = bwd_layer_start(L, PREC);
     constexpr int PPF = ppf(PREC);
     static_assert(kBwdLayers[L].nt == NT && kBwdLayers[L].nks == NKS, "bwd layer shape mismatch");
     auto piece_off = [](int g) { return ((g / kChunkPieces) % kSlots) * kChunkBytes + (g % kChunkPieces) * kPieceBytes; };
+    // ds_read offsets are 16-bit immediates and the ring is 96 KiB: pieces of its last third are addressed from a second base
+    // register (left to itself hipcc materialises one address VGPR per such piece — dozens of live registers)
+    // (`lds_hi` is opaque to the optimiser: it would fold the constant back into one address per piece)
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+    auto piece_ptr = [&](int g) { return piece_off(g) < 65536 ? (lds_cptr)(lds_lo + (unsigned)piece_off(g)) : (lds_cptr)(lds_hi + (unsigned)(piece_off(g) - 65536)); };
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
         gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
@@ -211,12 +216,12 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char*
             const int g = G0 + (t * NKS + ks) * PPF;
             if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
             if constexpr (PREC == NERFHIP_BF16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem_lane + piece_off(g));
+                const bf16x8 a = *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>(piece_ptr(g));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gin[ks], acc, 0, 0, 0);
             } else {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g));
+                const f32x4 a0 = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(piece_ptr(g));
                 if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem_lane + piece_off(g + 1));
+                const f32x4 a1 = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(piece_ptr(g + 1));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], gin[ks][j], acc, 0, 0, 0);
 #pragma unroll
@@ -278,13 +283,17 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const char*
         }
         }
         if constexpr (!F8) {
+            // per-layer descriptor: the (possibly runtime, wave-uniform) section offset sits in its SALU-computed base, the
+            // per-tile offsets are immediates (soffset stays 0: gfx950 store-data hazard, see store_slab)
+            __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab), 0,
+                                                                              (int)(2 * NT * 64 * sizeof(Slab)), 0x00020000);
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) store_slab(st, dys, dy_sec + 2 * t + sl, out[2 * t + sl], lane);
+            for (int sl = 0; sl < 2; ++sl) store_slab(st, dys_l, 2 * t + sl, out[2 * t + sl], lane);
         }
     });
     if constexpr (F8 && PREC == NERFHIP_BF16) {
         const int sb = dy_block_scale(mx);
-        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), f8_dy_section(dy_sec), sb, lane);
+        save_scale_f8(st.pending, dy_tile, f8_dy_scale_off(), dy_scale_idx, sb, lane);
         return sb;
     }
     return 127;
@@ -337,7 +346,10 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     st.pending_prev = 0;
     st.issue_chunk(0);
     st.issue_chunk(1);
-    const char* smem_lane = ring + lane * 16;
+    // this lane's 16 bytes of every piece: LDS byte address of the ring's first 64 KiB and (opaque) of the rest
+    const unsigned lds_lo = (unsigned)(uintptr_t)ring + (unsigned)lane * 16u;
+    unsigned lds_hi = lds_lo + 65536u;
+    asm volatile("" : "+v"(lds_hi));
 
     // d sigmoid: g_a_rgb = g_rgb * rgb * (1 - rgb)      (nerf.py:79-81, 120);  sigma is linear (nerf.py:112)
     float v[8];
@@ -381,18 +393,47 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     Slab ga[17], gb[17];
     // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)  -> dY_dir in gd
     Slab g_in0[1] = {g_rgb};
-    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, smem_lane, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
-                                                          -1, 127, lane);
+    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, lds_lo, lds_hi, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
+                                                          f8_dy_section(kDyDir), -1, 127, lane);
     // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga   (F8: stores its input dY_dir)
-    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, smem_lane, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, kDyDir, sb, lane);
+    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, lds_lo, lds_hi, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, f8_dy_section(kDyFeat),
+                                                       kDyDir, sb, lane);
     ga[16] = g_sig;
     // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (F8: stores dY_feat)
-    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, smem_lane, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
-                                                       kDyFeat, sb, lane);
-#define NH_BWD(L, IN, OUT)                                                                                                  \
-    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, smem_lane, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
-                                                       mask_piece_h(10 - L), dys, dy_tile, dy_h(10 - L), dy_h(11 - L), sb, lane);
-    NH_BWD(3, gb, ga) NH_BWD(4, ga, gb) NH_BWD(5, gb, ga) NH_BWD(6, ga, gb) NH_BWD(7, gb, ga) NH_BWD(8, ga, gb) NH_BWD(9, gb, ga)
+    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, lds_lo, lds_hi, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
+                                                       f8_dy_section(dy_h(8)), kDyFeat, sb, lane);
+    // ---- layers 3..8 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
+    // straight-line code against a 64 KiB instruction cache (profiles/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel
+    // over that size runs 1.5x slower for its instruction fetches alone).  A 256 x 256 layer is 4 chunks of the W^T stream, so
+    // three layers later the stream is at the same piece offset within a chunk AND in the same ring slot (12 chunks = 0 mod 3):
+    // the second pass differs only in wave-uniform values — the stream pointer (+12 chunks), the gate piece (-3), the dY
+    // sections (+48 slabs) and scale dwords (+3).  Three layers flip the ga / gb ping-pong, so each pass ends by copying its
+    // result back (64 register moves per 384 MFMAs).
+    static_assert(bwd_layer_pieces(3, PREC) * 3 % (kChunkPieces * kSlots) == 0, "three looped layers = a whole number of ring turns");
+#define NH_BWD(L, IN, OUT, D)                                                                                                \
+    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, lds_lo, lds_hi, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
+                                                       mask_piece_h(10 - L) - (D), dys, dy_tile, dy_h(10 - L) + 16 * (D),            \
+                                                       f8_dy_section(dy_h(10 - L)) + (D), dy_h(11 - L) + 16 * (D), sb, lane);
+    {
+        const uint8_t* const gsrc0 = st.gsrc;
+        int n_pass;
+        asm volatile("s_mov_b32 %0, 2" : "=s"(n_pass));          // opaque trip count: the loop must stay a loop
+#pragma clang loop unroll(disable)
+        for (int pass = 0; pass < n_pass; ++pass) {
+            // (the store counters restart from 0 in every pass: under-counting only over-waits at the first boundaries)
+            st.pending = 0;
+            st.pending_prev = 0;
+            const int d = 3 * pass;                              // layers the pass is ahead of the code's constants
+            NH_BWD(3, gb, ga, d) NH_BWD(4, ga, gb, d) NH_BWD(5, gb, ga, d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gb[i] = ga[i];
+            st.gsrc += (size_t)(3 * bwd_layer_pieces(3, PREC)) * kPieceBytes;
+        }
+        st.pending = 0;
+        st.pending_prev = 0;
+        st.gsrc = gsrc0;
+    }
+    NH_BWD(9, gb, ga, 0)
 #undef NH_BWD
     if constexpr (F8 && PREC == NERFHIP_BF16) {              // the last section (dY_1) has no consuming layer: flush it
 #pragma unroll

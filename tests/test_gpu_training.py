@@ -44,14 +44,14 @@ def test_mlp_backward_embedded_vs_autograd(dev, dtype, tol, n):
             assert err <= tol * r.abs().max().item() + 1e-7, (dtype, n, name, err, r.abs().max().item())
         else:
             # reduced precision: the DIRECTION of every gradient tensor (the bound of tests/test_gpu_bf16.py, here also at the
-            # ragged sizes n = 1, 33, 300): cosine >= 0.99 for bf16, >= 0.98 with the 8-bit dW operands (>= 0.975 for n < 64); the relative L2 error
+            # ragged sizes n = 1, 33, 300): cosine >= 0.99 for bf16, >= 0.98 with the 8-bit dW operands (>= 0.98 for both at n = 1); the relative L2 error
             # (0.1-11 % measured, deepest layers worst: the bf16 FORWARD activations, hence ReLU gates, already differ from the
             # fp32 oracle's) is printed, not gated
             rel = (gq - r).norm().item() / (r.norm().item() + 1e-12)
             cos = torch.nn.functional.cosine_similarity(gq.flatten(), r.flatten(), dim=0).item()
             worst = min(worst, cos)
-            # (n < 64: a handful of points, nothing averages — measured minimum 0.987 at n = 1)
-            assert cos >= ((0.99 if dtype == "bf16" else 0.98) if n >= 300 else 0.975), (dtype, n, name, rel, cos)
+            # (n = 1: a single point, nothing averages — measured 0.987 / 0.985; n = 33: 0.991 / 0.983)
+            assert cos >= ((0.99 if dtype == "bf16" else 0.98) if n >= 33 else 0.98), (dtype, n, name, rel, cos)
     if dtype != "fp32":
         print("worst per-tensor gradient cosine, %s n=%d: %.4f" % (dtype, n, worst))
 

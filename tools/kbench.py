@@ -30,6 +30,28 @@ def timed(fn, reps):
     return sum(ts) / len(ts), ts[0]
 
 
+def merged(a, dev, m_fine):
+    B = a.rays
+    rays = O.make_rays(1, B, "blender").to(dev)
+    m_coarse = NeRF()
+    m_coarse.load_state_dict(O.make_params(100, 4.0, 0.2))
+    m_coarse.mlp_dtype = a.dtype
+    m_coarse = m_coarse.to(dev)
+    entries = []
+    for m, S in ((m_fine, a.samples), (m_coarse, 64)):
+        z = torch.sort(2 + 4 * torch.rand(B, S, device=dev), -1)[0]
+        acts = ops.alloc_acts(B * S, a.dtype, dev)
+        pk, pb = m.packed_weights_train(a.dtype)
+        out = ops.mlp_fwd_rays(rays, z, pk, False, a.dtype, save=acts)
+        entries.append((torch.randn_like(out), out, pb, acts))
+    ws = {}
+    ops.mlp_bwd_multi(entries, a.dtype, workspace=ws)                       # chains: fill the dY slabs
+    d_avg, d_min = timed(lambda: ops.mlp_bwd_multi(entries, a.dtype, phases=2, workspace=ws), a.reps)
+    r_avg, r_min = timed(lambda: ops.mlp_bwd_multi(entries, a.dtype, phases=4, workspace=ws), a.reps)
+    print("%s merged %dx(%d+64) %s: dW %.1f (min %.1f)  reduce %.1f (min %.1f) us"
+          % (os.path.basename(os.environ.get("NERFHIP_LIB_PATH", "libnerfhip.so")), B, a.samples, a.dtype, d_avg, d_min, r_avg, r_min), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=1024)
@@ -37,6 +59,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--interleaved", action="store_true")
+    ap.add_argument("--merged", action="store_true",
+                    help="only the launches the fused training step shares between its two models: ONE dW launch + ONE reduce launch over "
+                         "a fine pass of --samples and a coarse pass of 64 samples per ray")
     ap.add_argument("--clock-probe", action="store_true",
                     help="library built with -DNERFHIP_CLOCK_PROBE=1, --dtype bf16_f8: shader clock and cycles of the saving forward")
     a = ap.parse_args()
@@ -46,6 +71,8 @@ def main():
     m.mlp_dtype = a.dtype
     m = m.to(dev)
     B, S = a.rays, a.samples
+    if a.merged:
+        return merged(a, dev, m)
     rays = O.make_rays(1, B, "blender").to(dev)
     z = torch.sort(2 + 4 * torch.rand(B, S, device=dev), -1)[0]
     packed = m.packed_weights(a.dtype)

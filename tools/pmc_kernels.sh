@@ -12,6 +12,9 @@ for D in $DTYPES; do
       timeout 150 rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/pmc_${D}_${S}_$C -o p -- python $REPO/tools/kbench.py --dtype $D --samples $S --reps 2 > /dev/null 2> $OUT/pmc_${D}_${S}_$C.log
     done
   done
+  for C in FETCH_SIZE WRITE_SIZE; do          # the merged dW / reduce launches of the fused step (fine 192 + coarse 64 samples per ray)
+    timeout 150 rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/pmc_${D}_merged_$C -o p -- python $REPO/tools/kbench.py --dtype $D --samples 192 --merged --reps 2 > /dev/null 2> $OUT/pmc_${D}_merged_$C.log
+  done
 done
 cd $REPO
 python tools/pmc_kernels_summary.py $OUT $DTYPES

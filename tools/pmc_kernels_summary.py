@@ -14,11 +14,11 @@ KEYS = {"mlp_fwd_kernel": None, "mlp_bwd_chain_kernel": "mlp_bwd_chain_kernel", 
         "mlp_bwd_dw_kernel": "mlp_bwd_dw_kernel", "mlp_bwd_reduce_kernel": "mlp_bwd_reduce_kernel"}
 res = {}
 for d in dtypes:
-    for S in (192, 64):
-        P = 1024 * S
+    for S in (192, 64, "merged"):
+        P = 1024 * (192 + 64) if S == "merged" else 1024 * S
         vals = collections.defaultdict(dict)
         for C in ("FETCH_SIZE", "WRITE_SIZE"):
-            fs = glob.glob(os.path.join(out_dir, "pmc_%s_%d_%s" % (d, S, C), "**", "*counter_collection.csv"), recursive=True)
+            fs = glob.glob(os.path.join(out_dir, "pmc_%s_%s_%s" % (d, S, C), "**", "*counter_collection.csv"), recursive=True)
             if not fs:
                 continue
             per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -34,6 +34,8 @@ for d in dtypes:
             base = name.split("<")[0]
             if base not in KEYS or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
                 continue
+            if S == "merged" and base not in ("mlp_bwd_dw_f8_kernel", "mlp_bwd_dw_kernel", "mlp_bwd_reduce_kernel"):
+                continue                       # (its forwards and chains are per-model launches, measured above)
             if base == "mlp_fwd_kernel":
                 # template args <PREC, MODE, SIGMA_ONLY, SV>: SV 0 = inference, 1/2 = activation-saving
                 args = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
@@ -42,10 +44,12 @@ for d in dtypes:
                 key = "mlp_fwd_kernel" if args[3] in ("0", "false") else "mlp_fwd_kernel<save>"
             else:
                 key = KEYS[base]
+            if S == "merged":
+                key += "<merged>"
             res["%s|%s|%d" % (key, d, P)] = {
                 "FETCH_SIZE_KB": round(cs["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(cs["WRITE_SIZE"], 1),
                 "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024), "kernel": name,
-                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/kbench.py --dtype %s --samples %d" % (d, S)}
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/kbench.py --dtype %s --samples %s" % (d, "192 --merged" if S == "merged" else S)}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_pl_amd.build import source_digest  # noqa: E402
 out = dict(res)

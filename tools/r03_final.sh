@@ -1,0 +1,24 @@
+# Round-3 evidence set (run ON THE GPU BOX through gpurun): everything profiles/README.md "Round 3" quotes, one box, one call
+set -u
+OUT=gpurun_out/r03final; mkdir -p $OUT
+REPO=$(pwd)
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+tools/ktrace_step.sh r03final/trace > $OUT/kernel_by_grid.txt 2>&1
+python bench.py --dtype bf16 --no-cpu-baseline --no-extras > $OUT/bench_train_bf16_storage.json 2>/dev/null
+python bench.py --dtype fp32 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_train_fp32.json 2>/dev/null
+python bench.py --mode render --no-cpu-baseline > $OUT/bench_render.json 2>/dev/null
+python bench.py --mode eval --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_eval.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extras --modular-step > $OUT/bench_modular_step.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extras --no-fuse-adam > $OUT/bench_no_fuse_adam.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extras --force-dist --sync-in-graph 1 > $OUT/bench_rccl_world1_one_graph.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extras --force-dist --sync-in-graph 0 > $OUT/bench_rccl_world1_two_graphs.json 2>/dev/null
+tools/pmc_kernels.sh r03final/pmc bf16_f8 > $OUT/pmc_traffic.txt 2>&1
+for f in $OUT/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['dtype'])
+except Exception as e: print(sys.argv[1], 'FAILED', e)
+PY
+done
+timeout 420 python tools/psnr_gate.py --gate --out $OUT/psnr_gate.json > $OUT/psnr_gate.log 2>&1; grep -E '"mean"|"stderr"|fp32"' $OUT/psnr_gate.log | tail -8
+ls $OUT
