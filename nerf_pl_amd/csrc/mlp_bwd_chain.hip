@@ -186,7 +186,8 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
 // spread over the tiles, under the scale byte `in_sb` computed by ONE reduction at the end of the layer that produced it)
 // and returns the scale byte of its own output.
 template <int PREC, int L, int NT, int NKS, bool MASK, bool F8, int IN_PAIRS, typename Slab>
-__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsigned lds_lo, const unsigned lds_hi, const Slab (&gin)[NKS], Slab* out,
+__device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsigned lds_lo, const unsigned lds_hi, const unsigned sig_lds,
+                                                const Slab (&gin)[NKS == 17 ? 16 : NKS], Slab* out,
                                                 __amdgpu_buffer_rsrc_t acts, int gate_off, int mask_piece,
                                                 __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int dy_scale_idx, int in_sec,
                                                 int in_sb, int lane) {
@@ -199,6 +200,15 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
     // (`lds_hi` is opaque to the optimiser: it would fold the constant back into one address per piece)
     typedef __attribute__((address_space(3))) const char* lds_cptr;
     auto piece_ptr = [&](int g) { return piece_off(g) < 65536 ? (lds_cptr)(lds_lo + (unsigned)piece_off(g)) : (lds_cptr)(lds_hi + (unsigned)(piece_off(g) - 65536)); };
+    // B operand of slab step ks: the layer's register slabs; the 17th slab of the final^T + sigma^T layer (the sigma head's
+    // gradient) is re-read from the wave's LDS stash for every tile instead of living in four more registers through the one
+    // layer that is already the register-pressure peak of the kernel (17 + 16 slabs live)
+    auto bslab = [&](int ks) -> Slab {
+        if constexpr (NKS == 17) {
+            if (ks == 16) return *reinterpret_cast<__attribute__((address_space(3))) const Slab*>(sig_lds);
+        }
+        return gin[ks < (NKS == 17 ? 16 : NKS) ? ks : 0];
+    };
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
         gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
@@ -217,15 +227,16 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
             if (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
             if constexpr (PREC == NERFHIP_BF16) {
                 const bf16x8 a = *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>(piece_ptr(g));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gin[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bslab(ks), acc, 0, 0, 0);
             } else {
                 const f32x4 a0 = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(piece_ptr(g));
                 if ((g + 1) % kChunkPieces == 0) st.boundary((g + 1) / kChunkPieces);
                 const f32x4 a1 = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(piece_ptr(g + 1));
+                const Slab bs = bslab(ks);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], gin[ks][j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bs[j], acc, 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], gin[ks][4 + j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc, 0, 0, 0);
             }
         }
         if constexpr (F8 && PREC == NERFHIP_BF16) {                  // this tile's share of the INPUT section's pairs
@@ -310,7 +321,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     constexpr int kGateOff = F8 ? f8_act_gate_off() : act_mask_off(PREC);
     constexpr int kDyTile = F8 ? f8_dy_tile_bytes() : kDySlabs * 64 * (int)sizeof(Slab);
     constexpr int NW = BwdTraits<PREC>::NW;
-    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes];
+    __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * 64 * (int)sizeof(Slab)];      // W^T ring | sigma-slab stash
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
@@ -350,6 +361,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     const unsigned lds_lo = (unsigned)(uintptr_t)ring + (unsigned)lane * 16u;
     unsigned lds_hi = lds_lo + 65536u;
     asm volatile("" : "+v"(lds_hi));
+    const unsigned sig_lds = (unsigned)(uintptr_t)ring + (unsigned)(kSlots * kChunkBytes) + (unsigned)((wave * 64 + lane) * (int)sizeof(Slab));
 
     // d sigmoid: g_a_rgb = g_rgb * rgb * (1 - rgb)      (nerf.py:79-81, 120);  sigma is linear (nerf.py:112)
     float v[8];
@@ -390,17 +402,18 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
 
     // scale bytes of the sections produced so far (F8); rgb / sigma pairs were stored above
     Slab gd[8];
-    Slab ga[17], gb[17];
+    Slab ga[16], gb[16];
     // rgb^T : g_t = W_rgb^T g_a_rgb ; mask with t = relu(dir pre-act)  -> dY_dir in gd
     Slab g_in0[1] = {g_rgb};
-    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, lds_lo, lds_hi, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
+    int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, lds_lo, lds_hi, sig_lds, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
                                                           f8_dy_section(kDyDir), -1, 127, lane);
     // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga   (F8: stores its input dY_dir)
-    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, lds_lo, lds_hi, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, f8_dy_section(kDyFeat),
+    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, lds_lo, lds_hi, sig_lds, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, f8_dy_section(kDyFeat),
                                                        kDyDir, sb, lane);
-    ga[16] = g_sig;
+    // (the sigma head's slab is the 17th K slab of the next layer: parked in LDS, see run_bwd_layer_tm)
+    *reinterpret_cast<__attribute__((address_space(3))) Slab*>(sig_lds) = g_sig;
     // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (F8: stores dY_feat)
-    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, lds_lo, lds_hi, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
+    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, lds_lo, lds_hi, sig_lds, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
                                                        f8_dy_section(dy_h(8)), kDyFeat, sb, lane);
     // ---- layers 3..8 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
     // straight-line code against a 64 KiB instruction cache (profiles/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel
@@ -411,10 +424,14 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     // result back (64 register moves per 384 MFMAs).
     static_assert(bwd_layer_pieces(3, PREC) * 3 % (kChunkPieces * kSlots) == 0, "three looped layers = a whole number of ring turns");
 #define NH_BWD(L, IN, OUT, D)                                                                                                \
-    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, lds_lo, lds_hi, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
+    sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, lds_lo, lds_hi, sig_lds, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
                                                        mask_piece_h(10 - L) - (D), dys, dy_tile, dy_h(10 - L) + 16 * (D),            \
                                                        f8_dy_section(dy_h(10 - L)) + (D), dy_h(11 - L) + 16 * (D), sb, lane);
-    {
+    if constexpr (PREC != NERFHIP_BF16) {
+        // exact-fp32 variant (the parity configuration, one wave per SIMD): fully unrolled — its code is far beyond the instruction
+        // cache either way (186 vs 124 KB) and the loop costs it 27 spilled registers
+        NH_BWD(3, gb, ga, 0) NH_BWD(4, ga, gb, 0) NH_BWD(5, gb, ga, 0) NH_BWD(6, ga, gb, 0) NH_BWD(7, gb, ga, 0) NH_BWD(8, ga, gb, 0)
+    } else {
         const uint8_t* const gsrc0 = st.gsrc;
         int n_pass;
         asm volatile("s_mov_b32 %0, 2" : "=s"(n_pass));          // opaque trip count: the loop must stay a loop
