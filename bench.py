@@ -253,7 +253,7 @@ def event_time(fn, reps, warm=3, graph=False):
 
 def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     """Per-kernel roofline entries for the MLP kernels of the TIMED training step (fine pass B x (S+N) points and coarse
-    pass B x S points): HIP-event time of each kernel launched alone on resident buffers, algorithmic FLOPs and HBM bytes
+    pass B x S points): HIP-event time of each kernel on resident buffers, algorithmic FLOPs and HBM bytes
     (DESIGN.md §6), fractions of the dense MFMA peak of the kernel's arithmetic and of the 8 TB/s HBM peak.
     merged: the step runs ONE weight-gradient launch and ONE reduce launch for both models (the fused step at N = 1)."""
     from nerf_pl_amd import _lib, ops
@@ -265,17 +265,10 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         z = ops.sample_coarse_z(rays, S, False, 0.0)
         zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
 
+    todo = []                          # (name, tag, P, fn, flops, nbytes, what, key): timed together below, in the step's order
+
     def entry(name, tag, P, fn, flops, nbytes, what, key_name=None):
-        avg, mn = event_time(fn, 12, graph=True)
-        tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
-        # the dW GEMM of bf16_f8 runs on the MX-scaled fp8 MFMA: priced against ITS dense peak
-        peak = PEAK_TFLOPS_FP8 if (dtype == "bf16_f8" and name.startswith("mlp_bwd_dw")) else PEAK_TFLOPS[dtype]
-        fm, fh = tf / peak, gbs / PEAK_HBM_GBS
-        key = "%s|%s|%d" % (key_name or name, dtype, P)
-        out.append({"kernel": "%s<%s> %s, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
-                    "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
-                    "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_peak_tflops": peak, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
-                    "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
+        todo.append((name, tag, P, fn, flops, nbytes, what, key_name or name))
 
     keep, entries, dw_b, P_all = [], [], 0, 0
     for tag, model, zz in (("fine pass", models[1], zf), ("coarse pass", models[0], z)):
@@ -317,8 +310,35 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
               FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>")
         entry("mlp_bwd_reduce_kernel", "both models in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=4, workspace=wsm),
               0, ws_b + 4 * 595844 * 4, "split-K partial slabs read, 48 gradient tensors written", key_name="mlp_bwd_reduce_kernel<merged>")
-    del keep, entries
-    return out
+    # Timing: each kernel replayed alone (12 launches captured in a hipGraph: no host gaps).  One kernel repeated back to back
+    # settles at its own shader clock, which on some boxes is LOWER than inside the step's mix of MFMA-bound and HBM-bound kernels
+    # (HIP events between the nodes of one graph do not time on this stack: hipErrorInvalidHandle); the six kernels are therefore
+    # also replayed TOGETHER, in the step's order, from one graph: `mix_us` = their time per round in the step's own clock mix.
+    order = sorted(range(len(todo)), key=lambda i: (0 if "fwd" in todo[i][0] and "coarse" in todo[i][1] else
+                                                    1 if "fwd" in todo[i][0] else
+                                                    2 if "chain" in todo[i][0] and "fine" in todo[i][1] else
+                                                    3 if "chain" in todo[i][0] else 4 if "dw" in todo[i][0] else 5, i))
+    times = [event_time(todo[i][3], 12, graph=True) for i in order]
+
+    def one_round():
+        for i in order:
+            todo[i][3]()
+    mix_us = event_time(one_round, 4, graph=True)[0]
+    for k, i in enumerate(order):
+        name, tag, P, _, flops, nbytes, what, key_name = todo[i]
+        avg, mn = times[k]
+        tf, gbs = flops / avg / 1e6, nbytes / avg / 1e3
+        # the dW GEMM of bf16_f8 runs on the MX-scaled fp8 MFMA: priced against ITS dense peak
+        peak = PEAK_TFLOPS_FP8 if (dtype == "bf16_f8" and name.startswith("mlp_bwd_dw")) else PEAK_TFLOPS[dtype]
+        fm, fh = tf / peak, gbs / PEAK_HBM_GBS
+        key = "%s|%s|%d" % (key_name, dtype, P)
+        out.append({"kernel": "%s<%s> %s, %d points" % (name, dtype, tag, P), "avg_launch_us": round(avg, 1),
+                    "min_launch_us": round(mn, 1), "flops": flops, "hbm_bytes": nbytes, "bytes_are": what,
+                    "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_peak_tflops": peak, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                    "bound": "mfma" if fm >= fh else "hbm", "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
+    out.sort(key=lambda r: -r["avg_launch_us"])
+    del keep, entries, todo
+    return out, round(mix_us, 1)
 
 
 def main():
@@ -534,7 +554,7 @@ def main():
                                       "source": "profiles/r02_probe_mfma_rate.txt"}
         if a.mode == "train":
             # ---- the kernels the TIMED step runs, one entry each; `roofline` = the one that takes the most time ----
-            table = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db, merged=(system.fused_train_step and grad_sync is None))
+            table, mix_us = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db, merged=(system.fused_train_step and grad_sync is None))
             dom = max(table, key=lambda r: r["avg_launch_us"])
             roof = {"bound": dom["bound"], "kernel": dom["kernel"],
                     "achieved": dom["gbs"] if dom["bound"] == "hbm" else dom["tflops"],
@@ -546,7 +566,10 @@ def main():
             extra["roofline"] = roof
             extra["roofline_kernels"] = table
             extra["roofline_north_star"] = ns
-            extra["mlp_kernels_us_per_step"] = round(sum(r["avg_launch_us"] for r in table), 1)    # <= ms_per_step * 1000
+            # the step's MLP kernels replayed together in step order from one graph (<= ms_per_step * 1000) / summed from the
+            # kernel-alone entries (each at its own clock: may come out above or below the former, box dependent)
+            extra["mlp_kernels_us_per_step"] = mix_us
+            extra["mlp_kernels_us_alone_sum"] = round(sum(r["avg_launch_us"] for r in table), 1)
             # whole-step MFMA fraction: algorithmic FLOPs of the step (GEMMs only) over the step time
             step_flops = (FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW) * B * (2 * S + N)
             extra["step_frac_mfma"] = round(step_flops / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
