@@ -52,6 +52,13 @@ int nerfhip_posenc(const float* x, float* out, int64_t n, int C, int n_freqs, ne
 int nerfhip_posenc_bwd(const float* x, const float* gout, float* gx, int64_t n, int C, int n_freqs,
                        nerfhip_stream_t stream);
 
+/* The same with explicit frequency bands (bands: n_freqs DEVICE floats; NULL = the 2^k above): the reference's
+ * `Embedding(..., logscale=False)` = torch.linspace(1, 2^(F-1), F) (nerf.py:16-19), passed as the module built them.   */
+int nerfhip_posenc_bands(const float* x, const float* bands, float* out, int64_t n, int C, int n_freqs,
+                         nerfhip_stream_t stream);
+int nerfhip_posenc_bands_bwd(const float* x, const float* bands, const float* gout, float* gx, int64_t n, int C, int n_freqs,
+                             nerfhip_stream_t stream);
+
 /* ---- a5. coarse depth sampling  (models/rendering.py:183-204) --------------------------
  * rays (B,8)=[o d near far]; z (B,S): linear in depth or disparity; when perturb>0,
  * stratified jitter with `perturb_rand` (B,S) ~ U[0,1) (the caller's torch.rand draw).     */

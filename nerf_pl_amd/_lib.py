@@ -25,6 +25,8 @@ SIGNATURES = {
     "nerfhip_error_string": [_int],
     "nerfhip_posenc": [_c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
     "nerfhip_posenc_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_posenc_bands": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
+    "nerfhip_posenc_bands_bwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
     "nerfhip_sample_coarse_z": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _f32, _c_void_p],
     "nerfhip_searchsorted_right": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],
     "nerfhip_searchsorted_left": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _c_void_p],

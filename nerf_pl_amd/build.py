@@ -93,11 +93,12 @@ def _digest(src, flags):
 
 
 def source_digest():
-    """One digest of everything the kernels are built from (csrc/*, the C header, the flags): measurements taken on one build
-    (profiles/pmc_traffic.json) are stamped with it, and bench.py refuses counters stamped with another."""
+    """One digest of everything the MLP kernels are built from (csrc/mlp_*, the headers they include, the flags): measurements
+    taken on one build (profiles/pmc_traffic.json: HBM traffic of the MLP kernels) are stamped with it, and bench.py refuses
+    counters stamped with another."""
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
-    files.append(os.path.join(ROOT, "include", "nerfhip.h"))
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+             if f.startswith("mlp_") or f in ("common.h", "f8_store.h", "adam_math.h")]
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
         with open(f, "rb") as fh:

@@ -190,48 +190,56 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     const int m32 = lane & 31, kk = lane >> 5;
     const int f32_off = (m32 >> 4) * SLAB_BYTES + (slab_nat_h(m32 & 15) * 32) * 32 + slab_nat_j(m32 & 15) * 4;
 
-    for (int64_t it = 0; it < my_tiles; ++it) {
-        // stage `it` landed (DEPTH-2 younger stages may still fly), everyone done with stage it-1
-        static_assert(PREC != NERFHIP_BF16 || LPW == 5, "counted vmcnt below assumes 5 DMAs per wave per stage");
-        if (PREC == NERFHIP_BF16 && DEPTH == 4)      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (PREC == NERFHIP_BF16 && DEPTH == 3) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else                                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue_stage(it + DEPTH - 1);
-        if (wave < n_ot) {
-            const char* st_base = ring + (it % DEPTH) * STAGE_BYTES;
-            const char* dy_base = st_base + (2 * wave) * SLAB_BYTES;
-            const char* x_base = st_base + jb.dy_slabs * SLAB_BYTES;
-            if constexpr (PREC == NERFHIP_BF16) {
+    // (one copy of the iteration loop per X-tile count, see mlp_bwd_dw_f8_kernel: straight-line X loop, next tile's LDS reads in
+    // flight under the current tile's MFMA)
+    auto run = [&](auto nxt_c) {
+        constexpr int NXT = decltype(nxt_c)::value;
+        for (int64_t it = 0; it < my_tiles; ++it) {
+            // stage `it` landed (DEPTH-2 younger stages may still fly), everyone done with stage it-1
+            static_assert(PREC != NERFHIP_BF16 || LPW == 5, "counted vmcnt below assumes 5 DMAs per wave per stage");
+            if (PREC == NERFHIP_BF16 && DEPTH == 4)      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (PREC == NERFHIP_BF16 && DEPTH == 3) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else                                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_stage(it + DEPTH - 1);
+            if (wave < n_ot) {
+                const char* st_base = ring + (it % DEPTH) * STAGE_BYTES;
+                const char* dy_base = st_base + (2 * wave) * SLAB_BYTES;
+                const char* x_base = st_base + jb.dy_slabs * SLAB_BYTES;
+                if constexpr (PREC == NERFHIP_BF16) {
+                    auto load_frag = [&](const char* pb, int q) {
+                        union { s16x4 h2[2]; bf16x8 v; } f;
+                        f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s0));
+                        f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s1));
+                        return f.v;
+                    };
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {                      // two 16-point k-steps per 32-point tile
-                    union { s16x4 h2[2]; bf16x8 v; } a;
-                    a.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 512 + tr_s0));
-                    a.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(dy_base + tr_off + q * 512 + tr_s1));
+                    for (int q = 0; q < 2; ++q) {                      // two 16-point k-steps per 32-point tile
+                        // software pipeline pinned with sched_barriers (see mlp_bwd_dw_f8_kernel): three tiles' reads ahead
+                        constexpr int RD = 4;
+                        const bf16x8 a = load_frag(dy_base, q);
+                        bf16x8 b[RD];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dbacc += (float)a.v[j];
+                        for (int x = 0; x < RD - 1; ++x)
+                            if (x < NXT) b[x] = load_frag(x_base + 2 * x * SLAB_BYTES, q);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int x = 0; x < kDwMaxXTiles; ++x) {
-                        if (x < n_xt) {
-                            union { s16x4 h2[2]; bf16x8 v; } b;
-                            b.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 512 + tr_s0));
-                            b.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4*)(x_base + 2 * x * SLAB_BYTES + tr_off + q * 512 + tr_s1));
-                            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[x], 0, 0, 0);
+                        for (int j = 0; j < 8; ++j) dbacc += (float)a[j];
+#pragma unroll
+                        for (int x = 0; x < NXT; ++x) {
+                            if (x + RD - 1 < NXT) b[(x + RD - 1) % RD] = load_frag(x_base + 2 * (x + RD - 1) * SLAB_BYTES, q);
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[x % RD], acc[x], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                }
-            } else {
+                } else {
 #pragma unroll 4
-                for (int ks = 0; ks < 16; ++ks) {                  // 2 points per k-step
-                    const int pt = 2 * ks + kk;
-                    const float a = *reinterpret_cast<const float*>(dy_base + f32_off + pt * 32);
-                    dbacc += a;
+                    for (int ks = 0; ks < 16; ++ks) {                  // 2 points per k-step
+                        const int pt = 2 * ks + kk;
+                        const float a = *reinterpret_cast<const float*>(dy_base + f32_off + pt * 32);
+                        dbacc += a;
 #pragma unroll
-                    for (int x = 0; x < kDwMaxXTiles; ++x) {
-                        if (x < n_xt) {
+                        for (int x = 0; x < NXT; ++x) {
                             const float b = *reinterpret_cast<const float*>(x_base + 2 * x * SLAB_BYTES + f32_off + pt * 32);
                             acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x], 0, 0, 0);
                         }
@@ -239,6 +247,13 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                 }
             }
         }
+    };
+    switch (n_xt) {
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 9: run(std::integral_constant<int, 9>{}); break;
+        default: run(std::integral_constant<int, 10>{}); break;          // 10 = kDwMaxXTiles (the skip layer)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
 
@@ -379,40 +394,64 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = 0x38383838;                                 // e4m3 1.0
 
-    for (int64_t it = 0; it < my_pairs; ++it) {
-        // stage `it` landed (DEPTH-2 younger stages of LPW + 1 DMAs may still fly), everyone done with stage it-1
-        if (DEPTH == 4)      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue_stage(it + DEPTH - 1);
-        if (wave < n_ot) {
-            const char* st_base = ring + (it % DEPTH) * STAGE_BYTES + rd_off;
-            const char* sc_base = ring + DEPTH * STAGE_BYTES + ((it % DEPTH) * 8 + wave) * SCALE_BYTES + H * 64;
-            auto load_frag = [&](int piece) {
-                i32x8 f;
-                const char* pb = st_base + piece * kPieceBytes;
+    // The iteration loop exists once per X-tile count of the jobs (2 first layer, 4 rgb head, 8 the 256 x 256 layers and the sigma
+    // head, 9 dir layer, 10 skip layer), chosen by ONE wave-uniform switch outside it: with n_xt a compile-time constant the X
+    // loop is straight-line code, the next tile's four transposing LDS reads are in flight while the current tile's MFMA issues,
+    // and the compiler schedules across tiles.  (With the runtime guard `if (x < n_xt)` every tile was a branch target of its own:
+    // 4 ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, ten times per iteration in the same registers — the kernel was bound by ten
+    // exposed LDS round trips per ring stage, not by HBM: "a workgroup's time follows its iteration count, not its bytes".)
+    auto run = [&](auto nxt_c) {
+        constexpr int NXT = decltype(nxt_c)::value;
+        for (int64_t it = 0; it < my_pairs; ++it) {
+            // stage `it` landed (DEPTH-2 younger stages of LPW + 1 DMAs may still fly), everyone done with stage it-1
+            if (DEPTH == 4)      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_stage(it + DEPTH - 1);
+            if (wave < n_ot) {
+                const char* st_base = ring + (it % DEPTH) * STAGE_BYTES + rd_off;
+                const char* sc_base = ring + DEPTH * STAGE_BYTES + ((it % DEPTH) * 8 + wave) * SCALE_BYTES + H * 64;
+                auto load_frag = [&](const char* pb) {
+                    i32x8 f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                        (__attribute__((address_space(3))) i32x2*)(pb + (q >> 1) * tile1 + (q & 1) * 256));
-                    f[2 * q] = v[0];
-                    f[2 * q + 1] = v[1];
-                }
-                return f;
-            };
-            const i32x8 a = load_frag(wave);
-            const int sa = *reinterpret_cast<const int*>(sc_base);
-            const int sx1 = *reinterpret_cast<const int*>(sc_base + 4), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
-            accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, 127);   // bias: dY x 1.0
+                    for (int q = 0; q < 4; ++q) {
+                        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                            (__attribute__((address_space(3))) i32x2*)(pb + (q >> 1) * tile1 + (q & 1) * 256));
+                        f[2 * q] = v[0];
+                        f[2 * q + 1] = v[1];
+                    }
+                    return f;
+                };
+                const char* x_base = st_base + dyp * kPieceBytes;
+                // software pipeline, pinned with sched_barriers (left alone, hipcc sinks every tile's reads back to just before
+                // its MFMA: one exposed LDS round trip per tile): the reads of tiles x + 1 and x + 2 are in flight when MFMA x issues
+                constexpr int RD = 3;
+                const i32x8 a = load_frag(st_base + wave * kPieceBytes);
+                const int sa = *reinterpret_cast<const int*>(sc_base);
+                const int sx1 = *reinterpret_cast<const int*>(sc_base + 4), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
+                i32x8 b[RD];
+                b[0] = load_frag(x_base);
+                if (NXT > 1) b[1] = load_frag(x_base + kPieceBytes);
+                __builtin_amdgcn_sched_barrier(0);
+                accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, 127);   // bias: dY x 1.0
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int x = 0; x < kDwMaxXTiles; ++x) {
-                if (x < n_xt) {
-                    const i32x8 b = load_frag(dyp + x);
+                for (int x = 0; x < NXT; ++x) {
+                    if (x + 2 < NXT) b[(x + 2) % RD] = load_frag(x_base + (x + 2) * kPieceBytes);
+                    __builtin_amdgcn_sched_barrier(0);
                     // A = dY: e5m2 (cbsz 1), B = X: e4m3 (blgp 0); lanes 0..31 carry tile T0's section scales, lanes 32..63 T1's
-                    acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[x], NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, x < x1p ? sx1 : sx2);
+                    acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[x % RD], acc[x], NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, x < x1p ? sx1 : sx2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+    };
+    switch (n_xt) {
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 9: run(std::integral_constant<int, 9>{}); break;
+        default: run(std::integral_constant<int, 10>{}); break;          // 10 = kDwMaxXTiles (the skip layer)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
 

@@ -10,8 +10,10 @@ namespace nerfhip {
 constexpr int PE_PTS = 64;      // points per workgroup
 constexpr int PE_THREADS = 256;
 
-__global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             int64_t n, int C, int F) {
+// bands: NULL = the reference's default `logscale=True` bands 2^k (exact powers of two); else F explicit frequency bands (the
+// reference's `logscale=False`: torch.linspace(1, 2^(F-1), F), nerf.py:16-19, passed as the module built them)
+__global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float* __restrict__ x, const float* __restrict__ bands,
+                                                             float* __restrict__ out, int64_t n, int C, int F) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int OC = C * (2 * F + 1);
     const int64_t base = (int64_t)blockIdx.x * PE_PTS;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float* __restr
         int k = r / C, c = r - k * C;
         if (pt < npts) {
             float v = x[(base + pt) * C + c];
-            float arg = v * __builtin_ldexpf(1.0f, k);  // freq*x in fp32 first (exact: power of two)
+            float arg = v * (bands ? bands[k] : __builtin_ldexpf(1.0f, k));  // freq*x in fp32 first (logscale: exact power of two)
             float s, co;
             sincosf(arg, &s, &co);
             float* row = tile + pt * OC + C + 2 * C * k + c;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float* __restr
 }
 
 // gx[c] = g_id[c] + sum_k 2^k * (cos(2^k x) * g_sin[k,c] - sin(2^k x) * g_cos[k,c])
-__global__ __launch_bounds__(PE_THREADS) void posenc_bwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(PE_THREADS) void posenc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ bands,
                                                                  const float* __restrict__ gout,
                                                                  float* __restrict__ gx, int64_t n, int C, int F) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(PE_THREADS) void posenc_bwd_kernel(const float* __r
         const float* row = tile + pt * OC;
         float acc = row[c];
         for (int k = 0; k < F; ++k) {
-            float f = __builtin_ldexpf(1.0f, k);
+            float f = bands ? bands[k] : __builtin_ldexpf(1.0f, k);
             float s, co;
             sincosf(v * f, &s, &co);
             acc += f * (co * row[C + 2 * C * k + c] - s * row[C + 2 * C * k + C + c]);
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(PE_THREADS) void posenc_bwd_kernel(const float* __r
 
 }  // namespace nerfhip
 
-extern "C" int nerfhip_posenc(const float* x, float* out, int64_t n, int C, int n_freqs, nerfhip_stream_t stream) {
+extern "C" int nerfhip_posenc_bands(const float* x, const float* bands, float* out, int64_t n, int C, int n_freqs,
+                                    nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n >= 0 && C >= 1 && C <= 8 && n_freqs >= 0 && n_freqs <= 16);
     if (n == 0) return 0;
     NERFHIP_CHECK_ARG(x && out);
@@ -92,12 +95,15 @@ extern "C" int nerfhip_posenc(const float* x, float* out, int64_t n, int C, int 
     const int64_t blocks = (n + nerfhip::PE_PTS - 1) / nerfhip::PE_PTS;
     size_t lds = (size_t)nerfhip::PE_PTS * OC * sizeof(float);
     hipLaunchKernelGGL(nerfhip::posenc_kernel, dim3((unsigned)blocks), dim3(nerfhip::PE_THREADS), lds,
-                       (hipStream_t)stream, x, out, n, C, n_freqs);
+                       (hipStream_t)stream, x, bands, out, n, C, n_freqs);
     return nerfhip_launch_status();
 }
+extern "C" int nerfhip_posenc(const float* x, float* out, int64_t n, int C, int n_freqs, nerfhip_stream_t stream) {
+    return nerfhip_posenc_bands(x, nullptr, out, n, C, n_freqs, stream);
+}
 
-extern "C" int nerfhip_posenc_bwd(const float* x, const float* gout, float* gx, int64_t n, int C, int n_freqs,
-                                  nerfhip_stream_t stream) {
+extern "C" int nerfhip_posenc_bands_bwd(const float* x, const float* bands, const float* gout, float* gx, int64_t n, int C,
+                                        int n_freqs, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n >= 0 && C >= 1 && C <= 8 && n_freqs >= 0 && n_freqs <= 16);
     if (n == 0) return 0;
     NERFHIP_CHECK_ARG(x && gout && gx);
@@ -105,6 +111,10 @@ extern "C" int nerfhip_posenc_bwd(const float* x, const float* gout, float* gx, 
     const int64_t blocks = (n + nerfhip::PE_PTS - 1) / nerfhip::PE_PTS;
     size_t lds = (size_t)nerfhip::PE_PTS * OC * sizeof(float);
     hipLaunchKernelGGL(nerfhip::posenc_bwd_kernel, dim3((unsigned)blocks), dim3(nerfhip::PE_THREADS), lds,
-                       (hipStream_t)stream, x, gout, gx, n, C, n_freqs);
+                       (hipStream_t)stream, x, bands, gout, gx, n, C, n_freqs);
     return nerfhip_launch_status();
+}
+extern "C" int nerfhip_posenc_bwd(const float* x, const float* gout, float* gx, int64_t n, int C, int n_freqs,
+                                  nerfhip_stream_t stream) {
+    return nerfhip_posenc_bands_bwd(x, nullptr, gout, gx, n, C, n_freqs, stream);
 }

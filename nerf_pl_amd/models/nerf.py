@@ -27,13 +27,14 @@ class Embedding(nn.Module):
     def forward(self, x):
         """x: (B, in_channels) -> (B, out_channels).  Reference: models/nerf.py:21-38.
         One HIP launch (K1 posenc) instead of 41; channel order identical to the reference."""
-        if not self.logscale:
-            raise NotImplementedError("nerf_pl_amd.Embedding: only logscale=True (the reference's only use, "
-                                      "train.py:34-35) is implemented in the HIP kernel")
         if x.shape[-1] != self.in_channels:
             raise ValueError("expected %d input channels" % self.in_channels)
         lead = x.shape[:-1]
-        out = ops.posenc(x.reshape(-1, self.in_channels).float(), self.N_freqs)
+        # logscale=True (the reference's only use, train.py:34-35): the kernel forms the bands 2^k itself; logscale=False: the
+        # linspace bands of nerf.py:16-19 travel to the kernel as this module built them.  (The FUSED render_rays / NeRF path
+        # encodes in-register with the logscale bands only: models/rendering._fusable.)
+        bands = None if self.logscale else self.freq_bands
+        out = ops.posenc(x.reshape(-1, self.in_channels).float(), self.N_freqs, bands=bands)
         return out.reshape(*lead, self.out_channels)
 
 

@@ -30,14 +30,14 @@ def _c(t):
 # ------------------------------------------------------------------------------- posenc (a2)
 class _PosEnc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, n_freqs):
-        require_gpu(x)
+    def forward(ctx, x, n_freqs, bands):
+        require_gpu(x, bands)
         x = _c(x)
         n, C = x.shape
         out = torch.empty(n, C * (2 * n_freqs + 1), device=x.device, dtype=torch.float32)
-        check(_lib.load().nerfhip_posenc(ptr(x), ptr(out), n, C, n_freqs, stream_ptr()), "nerfhip_posenc")
+        check(_lib.load().nerfhip_posenc_bands(ptr(x), ptr(bands), ptr(out), n, C, n_freqs, stream_ptr()), "nerfhip_posenc")
         ctx.save_for_backward(x)
-        ctx.n_freqs = n_freqs
+        ctx.n_freqs, ctx.bands = n_freqs, bands
         return out
 
     @staticmethod
@@ -46,17 +46,22 @@ class _PosEnc(torch.autograd.Function):
         gout = _c(gout.float())
         gx = torch.empty_like(x)
         n, C = x.shape
-        check(_lib.load().nerfhip_posenc_bwd(ptr(x), ptr(gout), ptr(gx), n, C, ctx.n_freqs, stream_ptr()),
+        check(_lib.load().nerfhip_posenc_bands_bwd(ptr(x), ptr(ctx.bands), ptr(gout), ptr(gx), n, C, ctx.n_freqs, stream_ptr()),
               "nerfhip_posenc_bwd")
-        return gx, None
+        return gx, None, None
 
 
 @device_guard
-def posenc(x, n_freqs):
-    """Embedding.forward (reference models/nerf.py:21-38), logscale bands. x (n,C) -> (n, C(2F+1))."""
+def posenc(x, n_freqs, bands=None):
+    """Embedding.forward (reference models/nerf.py:21-38). x (n,C) -> (n, C(2F+1)).
+    bands None: the logscale bands 2^k; else a device tensor of n_freqs frequency bands (`logscale=False`, nerf.py:16-19)."""
     if x.dim() != 2:
         raise ValueError("posenc expects (n, C)")
-    return _PosEnc.apply(x, int(n_freqs))
+    if bands is not None:
+        if bands.numel() != int(n_freqs):
+            raise ValueError("posenc: need one band per frequency")
+        bands = bands.to(x.device, torch.float32).contiguous()
+    return _PosEnc.apply(x, int(n_freqs), bands)
 
 
 # ------------------------------------------------------------------------------- sampling (a5, a8-a10)

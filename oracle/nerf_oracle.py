@@ -86,16 +86,18 @@ def make_rays(seed, n, kind="blender"):
 
 
 # ----------------------------------------------------------------------------- a2: encoding
-def posenc(x, n_freqs):
-    """[x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]  nerf.py:33-38 (logscale bands :17).
+def posenc(x, n_freqs, logscale=True):
+    """[x, sin(f_0 x), cos(f_0 x), sin(f_1 x), ...]  nerf.py:33-38; bands f_k = 2^k (logscale, nerf.py:17) or
+    linspace(1, 2^(F-1), F) (nerf.py:19).
     Channel c: c<C -> x[c]; else k=(c-C)//(2C), sin if ((c-C)//C)%2==0 else cos."""
     x = x.float()
     n, C = x.shape
     out = torch.empty(n, C * (2 * n_freqs + 1), dtype=torch.float32)
     out[:, :C] = x
     col = C
+    bands = 2 ** torch.linspace(0, n_freqs - 1, n_freqs) if logscale else torch.linspace(1, 2 ** (n_freqs - 1), n_freqs)
     for k in range(n_freqs):
-        arg = x * float(2.0 ** k)  # fp32 product first, then sin/cos (SURVEY A.1)
+        arg = x * bands[k]  # fp32 product first, then sin/cos (SURVEY A.1)
         out[:, col:col + C] = torch.sin(arg)
         out[:, col + C:col + 2 * C] = torch.cos(arg)
         col += 2 * C

@@ -38,6 +38,28 @@ def test_posenc_ragged_and_large(dev):
     assert ops.posenc(torch.zeros(0, 3, device=dev), 10).shape == (0, 63)
 
 
+def test_embedding_linear_bands_vs_oracle(dev):
+    """Embedding(logscale=False) (nerf.py:16-19: bands linspace(1, 2^(F-1), F)) — forward and d/dx against the oracle, which
+    tests/test_oracle_vs_reference.py pins bit-for-bit to the real reference module."""
+    from nerf_pl_amd.models import Embedding
+    g = torch.Generator().manual_seed(8)
+    for n, F in ((1, 10), (130, 4), (1000, 6)):
+        x = (torch.rand(n, 3, generator=g) * 2 - 1) * 2.0
+        emb = Embedding(3, F, logscale=False)
+        assert torch.equal(emb.freq_bands, torch.linspace(1, 2 ** (F - 1), F))
+        x1 = x.clone().to(dev).requires_grad_(True)
+        out = emb(x1)
+        ref_in = x.clone().requires_grad_(True)
+        ref = O.posenc(ref_in, F, logscale=False)
+        assert torch.equal(out[:, :3].cpu(), ref[:, :3].detach())
+        assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 4e-7
+        go = torch.randn(ref.shape, generator=g)
+        (ref * go).sum().backward()
+        (out * go.to(dev)).sum().backward()
+        scale = ref_in.grad.abs().max().item()
+        assert (x1.grad.cpu() - ref_in.grad).abs().max().item() <= 2e-6 * scale + 1e-6
+
+
 def test_posenc_backward_vs_autograd(dev):
     """nerfhip_posenc_bwd == autograd through the oracle's Embedding restatement (nerf.py:21-38)."""
     from nerf_pl_amd import ops

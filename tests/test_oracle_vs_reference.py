@@ -31,6 +31,15 @@ def test_render_rays_live_reference(seed, kind, N_i, white, test_time, disp):
         assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), (k, (got[k] - ref[k]).abs().max().item())
 
 
+@pytest.mark.parametrize("logscale", [True, False])
+def test_embedding_live_reference(logscale):
+    """Embedding.forward incl. the `logscale=False` bands torch.linspace(1, 2^(F-1), F) (nerf.py:16-19): bit-equal."""
+    nerf, _ = ref_shim.load_reference()
+    x = torch.randn(57, 3, generator=torch.Generator().manual_seed(5)) * 3
+    for F in (10, 4, 6):
+        assert torch.equal(O.posenc(x, F, logscale), nerf.Embedding(3, F, logscale=logscale)(x))
+
+
 def test_ray_utils_live_reference():
     ru = ref_shim.load_reference_ray_utils()
     H, W, focal = 13, 17, 15.3
