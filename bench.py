@@ -616,6 +616,7 @@ def main():
                                      "fused node: composite+loss+composite-backward per pass, one pack / dW / reduce launch for both models"
                                      + (", Adam applied inside the reduce kernel" if system.fuse_adam else ", separate Adam launch")),
                        "rccl_nranks": rccl_nranks,
+                       "capture_fallback": (getattr(state["graphed"], "capture_fallback", None) if a.mode == "train" else None),
                        "grad_sync": (None if (grad_sync is None or a.mode != "train") else
                                      ("one hipGraph, all-reduces issued from the grad-ready hooks inside it"
                                       if (state["graphed"] is not None and not state["graphed"]._two_graphs()) else

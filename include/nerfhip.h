@@ -221,6 +221,30 @@ int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const fl
 int nerfhip_mlp_dx_embedded(const void* dys, int64_t n, const float* w_xyz1, const float* w_xyz5, const float* w_dir,
                             float* gx, int64_t gx_stride, int dtype, nerfhip_stream_t stream);
 
+/* ---- a3/a4 for a NON-default NeRF(D, W, in_channels_xyz, in_channels_dir, skips)  (models/nerf.py:42-124) ----
+ * The fused kernels above are built for the default shape.  Any other shape runs layer by layer through one MFMA GEMM
+ * kernel: activations (n, features) fp32 row-major with a row stride (ld*, in floats; unit column stride), weights (out, in)
+ * fp32 row-major with row stride ldw (so a column block of a weight — the two halves of a skip / direction concat,
+ * nerf.py:108-109,118 — is addressed by pointer offset + ldw).  dtype: NERFHIP_F32 exact fp32 MFMA; NERFHIP_BF16 and
+ * NERFHIP_BF16_F8: operands rounded to bf16, fp32 accumulation.
+ *   fwd         y[n, n_out] = act( x[n, n_in] . w[n_out, n_in]^T (+ y when accumulate) (+ bias when non-NULL) )
+ *   bwd_input   gx[n, n_in] (+)= (gy * act'(y))[n, n_out] . w[n_out, n_in]        act' from the layer OUTPUT y (ReLU: y > 0;
+ *                                                                                 Sigmoid: y (1 - y)); y unused for ACT_NONE
+ *   bwd_weight  gw[n_out, n_in] (+)= (gy * act'(y))^T . x;  gb[n_out] (+)= column sums (gb NULL: skipped).  Split over the
+ *               points into `workspace` (nerfhip_linear_bwd_weight_workspace_bytes) and reduced in a fixed order.          */
+#define NERFHIP_ACT_NONE 0
+#define NERFHIP_ACT_RELU 1
+#define NERFHIP_ACT_SIGMOID 2
+int nerfhip_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
+                       int64_t n, int n_in, int n_out, int act, int accumulate, int dtype, nerfhip_stream_t stream);
+int nerfhip_linear_bwd_input(const float* gy, int64_t ldgy, const float* y, int64_t ldy, int act, const float* w, int64_t ldw,
+                             float* gx, int64_t ldgx, int64_t n, int n_in, int n_out, int accumulate, int dtype,
+                             nerfhip_stream_t stream);
+size_t nerfhip_linear_bwd_weight_workspace_bytes(int64_t n, int n_in, int n_out);
+int nerfhip_linear_bwd_weight(const float* gy, int64_t ldgy, const float* y, int64_t ldy, int act, const float* x, int64_t ldx,
+                              float* gw, int64_t ldgw, float* gb, void* workspace, int64_t n, int n_in, int n_out,
+                              int accumulate, int dtype, nerfhip_stream_t stream);
+
 /* ---- N2. MSELoss.forward + psnr + backward seed  (losses.py:9-14, metrics.py:4-13, train.py:103-117) ----
  * rgb_coarse, rgb_fine (NULL when N_importance == 0), target: n = 3*rays floats each.
  * out3 = [loss, psnr of the fine (else coarse) image, its mse];  g_coarse / g_fine (NULL ok) receive

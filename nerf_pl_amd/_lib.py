@@ -76,6 +76,12 @@ SIGNATURES = {
     "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p, _c_void_p, _c_void_p],
+    "nerfhip_linear_fwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _int, _int, _int, _int, _int, _c_void_p],
+    "nerfhip_linear_bwd_input": [_c_void_p, _i64, _c_void_p, _i64, _int, _c_void_p, _i64, _c_void_p, _i64, _i64, _int, _int, _int,
+                                 _int, _c_void_p],
+    "nerfhip_linear_bwd_weight_workspace_bytes": [_i64, _int, _int],
+    "nerfhip_linear_bwd_weight": [_c_void_p, _i64, _c_void_p, _i64, _int, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
+                                  _i64, _int, _int, _int, _int, _c_void_p],
 }
 
 
@@ -88,7 +94,8 @@ class AdamFused(ctypes.Structure):
 _RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t,
              "nerfhip_mlp_act_bytes": ctypes.c_size_t, "nerfhip_mlp_packed_bwd_bytes": ctypes.c_size_t,
              "nerfhip_mlp_dy_bytes": ctypes.c_size_t, "nerfhip_mlp_dw_workspace_bytes": ctypes.c_size_t,
-             "nerfhip_mlp_dw_workspace_bytes_multi": ctypes.c_size_t}
+             "nerfhip_mlp_dw_workspace_bytes_multi": ctypes.c_size_t,
+             "nerfhip_linear_bwd_weight_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

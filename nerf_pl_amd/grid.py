@@ -13,7 +13,7 @@ from . import ops
 
 
 @torch.no_grad()
-def sigma_grid(model, N, x_range, y_range, z_range, rows_per_launch=1 << 16, clamp=True):
+def sigma_grid(model, N, x_range, y_range, z_range, rows_per_launch=1 << 16, clamp=True, embedding_xyz=None):
     """sigma (N, N, N) float32 on the device, indexed [iy, ix, iz] exactly like the reference's
     `np.maximum(rgbsigma[:, -1], 0).reshape(N, N, N)` built from `np.meshgrid(x, y, z)` (extract_color_mesh.py:118-140).
     `clamp=False` returns the raw density."""
@@ -25,8 +25,20 @@ def sigma_grid(model, N, x_range, y_range, z_range, rows_per_launch=1 << 16, cla
     rows[:, 0] = xs[ix.reshape(-1)]
     rows[:, 1] = ys[iy.reshape(-1)]
     rows[:, 5] = 1.0                                   # d = (0, 0, 1): point = (x + 0*z, y + 0*z, 0 + 1*z) exactly
-    packed = model.packed_weights()
     out = torch.empty(N * N, N, device=dev, dtype=torch.float32)
+    if not model.is_default_arch():
+        # non-default shape: the lattice rows go through Embedding + the layer-by-layer sigma-only forward (models/layered.py)
+        if embedding_xyz is None:
+            raise ValueError("sigma_grid of a non-default NeRF needs its xyz Embedding (embedding_xyz=)")
+        rows_per_launch = max(1, min(rows_per_launch, (1 << 22) // N))
+        for r0 in range(0, N * N, rows_per_launch):
+            r1 = min(N * N, r0 + rows_per_launch)
+            pts = torch.stack([rows[r0:r1, 0:1].expand(-1, N), rows[r0:r1, 1:2].expand(-1, N), zs[None, :].expand(r1 - r0, N)], -1)
+            out[r0:r1] = model(embedding_xyz(pts.reshape(-1, 3)), sigma_only=True).view(r1 - r0, N)
+        if clamp:
+            out.clamp_(min=0)
+        return out.view(N, N, N)
+    packed = model.packed_weights()
     for r0 in range(0, N * N, rows_per_launch):
         r1 = min(N * N, r0 + rows_per_launch)
         zv = zs[None, :].expand(r1 - r0, N).contiguous()

@@ -61,7 +61,8 @@ class NeRF(nn.Module):
         self.sigma = nn.Linear(W, 1)
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         # --- MI355X specifics (not part of state_dict) ---
-        self.mlp_dtype = default_mlp_dtype()    # 'fp32' (parity) | 'bf16' (roofline)
+        self.mlp_dtype = default_mlp_dtype()    # 'fp32' (parity) | 'bf16' | 'bf16_f8' (roofline); a non-default shape runs
+                                                # layer by layer (models/layered.py) and reads 'bf16_f8' as 'bf16'
         self._packed_cache = {}
 
     # -- fused-kernel plumbing -----------------------------------------------------------------
@@ -162,5 +163,11 @@ class NeRF(nn.Module):
     def forward(self, x, sigma_only=False):
         """x: (B, 63+27) embedded position+direction, or (B, 63) when sigma_only.
         Returns (B,4)=[rgb, sigma] or (B,1) sigma.  Reference: models/nerf.py:83-124."""
+        if not self.is_default_arch():
+            # any other D / W / skips / channel counts: one HIP GEMM launch per layer (models/layered.py, csrc/linear.hip)
+            from .layered import nerf_forward
+            lead = x.shape[:-1]
+            out = nerf_forward(self, x.reshape(-1, x.shape[-1]), bool(sigma_only))
+            return out.reshape(*lead, out.shape[-1])
         from .mlp_autograd import mlp_embedded
         return mlp_embedded(self, x, bool(sigma_only))

@@ -4,6 +4,11 @@
 order (models/rendering.py:58-244) but runs as 5 HIP launches per call:
     sample_coarse_z -> mlp(coarse) -> composite -> fine_z (sample_pdf + merge) -> mlp(fine) -> composite
 with points, encodings and the repeated direction embedding never materialised in HBM.
+
+That is the reference's configuration (NeRF D=8 W=256 skips=[4], Embedding(3,10)/(3,4) logscale: train.py:34-42).  Any other
+NeRF shape or embedding keeps the same pipeline with the MLP stage unfused (`_mlp_points`): points -> Embedding (posenc
+kernel) -> NeRF.forward layer by layer (csrc/linear.hip), in point chunks of `chunk` like the reference's loop
+(rendering.py:115-141).
 """
 import torch
 
@@ -33,6 +38,25 @@ def _fusable(models, embeddings):
         and embeddings[0].in_channels == 3 and embeddings[1].in_channels == 3
 
 
+def _mlp_points(model, embedding_xyz, rays, z, dir_embedded, sigma_only, chunk):
+    """raw (B,S,4) [or sigma (B,S)] of `model` at the points o + d z: the unfused MLP stage (rendering.py:115-141, :206).
+    Each chunk of `chunk` points is embedded, joined with the direction embedding of the ray that owns the point (a gather:
+    the S-fold repeat of rendering.py:119 is never materialised) and evaluated by NeRF.forward."""
+    B, S = z.shape
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(-1, 3)
+    n = B * S
+    outs = []
+    for lo in range(0, n, max(1, chunk)):
+        hi = min(n, lo + max(1, chunk))
+        e = embedding_xyz(pts[lo:hi])
+        if not sigma_only:
+            owner = torch.arange(lo, hi, device=z.device) // S
+            e = torch.cat([e, dir_embedded.index_select(0, owner)], 1)
+        outs.append(model(e, sigma_only=sigma_only))
+    out = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+    return out.view(B, S) if sigma_only else out.view(B, S, 4)
+
+
 def render_rays(models,
                 embeddings,
                 rays,
@@ -52,24 +76,28 @@ def render_rays(models,
     rays: (N_rays, 3+3+2) origins, directions, near, far.
     Returns dict with rgb_coarse/depth_coarse (unless test_time), opacity_coarse and, when
     N_importance>0, rgb_fine/depth_fine/opacity_fine.
-    `chunk` is accepted for signature compatibility; the fused kernel needs no point-chunk loop
-    (its only per-point HBM footprint is 4 B in + 16 B out).
+    `chunk`: the fused kernel needs no point-chunk loop (its only per-point HBM footprint is 4 B in + 16 B out); the
+    layer-by-layer path of non-default shapes evaluates `chunk` points per MLP call, as the reference does.
     """
-    if not _fusable(models, embeddings):
-        raise NotImplementedError(
-            "nerf_pl_amd.render_rays implements the reference configuration (NeRF D=8 W=256 skips=[4], "
-            "Embedding(3,10)/(3,4), train.py:34-42); other architectures have no HIP kernel")
     rays = rays.float().contiguous()
     N_rays = rays.shape[0]
     dev = rays.device
     model_coarse = models[0]
+    if _fusable(models, embeddings):
+        def mlp(model, z, sigma_only):
+            return mlp_rays(model, rays, z, sigma_only=sigma_only)
+    else:
+        dir_embedded = embeddings[1](rays[:, 3:6])                                          # :186 (raw rays_d, SURVEY A.3)
+
+        def mlp(model, z, sigma_only):
+            return _mlp_points(model, embeddings[0], rays, z, dir_embedded, sigma_only, int(chunk))
 
     # RNG: identical calls, order, shapes and device as the reference (SURVEY A.6)
     perturb_rand = torch.rand(N_rays, N_samples, device=dev) if perturb > 0 else None      # :203
     z_vals = ops.sample_coarse_z(rays, N_samples, use_disp, perturb, perturb_rand)          # :189-204
     noise_c = torch.randn(N_rays, N_samples, device=dev)                                    # :152 (always drawn)
 
-    raw_c = mlp_rays(model_coarse, rays, z_vals, sigma_only=bool(test_time))                # :206-217
+    raw_c = mlp(model_coarse, z_vals, bool(test_time))                                      # :206-217
     if test_time:
         weights_coarse, opacity_c = ops.composite(raw_c, z_vals, rays, noise_c, noise_std, white_back)
         result = {'opacity_coarse': opacity_c}
@@ -81,7 +109,7 @@ def render_rays(models,
         u = torch.rand(N_rays, N_importance, device=dev) if perturb != 0 else None          # :39, det=(perturb==0)
         z_fine = ops.fine_z(z_vals, weights_coarse.detach(), N_importance, u=u)             # :223-229 (.detach :226)
         noise_f = torch.randn(N_rays, N_samples + N_importance, device=dev)                 # :152
-        raw_f = mlp_rays(models[1], rays, z_fine, sigma_only=False)
+        raw_f = mlp(models[1], z_fine, False)
         _, opacity_f, rgb_f, depth_f = ops.composite(raw_f, z_fine, rays, noise_f, noise_std, white_back)
         result['rgb_fine'] = rgb_f
         result['depth_fine'] = depth_f

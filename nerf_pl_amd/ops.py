@@ -560,3 +560,86 @@ def mlp_bwd_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=N
         check(lib.nerfhip_mlp_bwd_multi(M, G, O, n_arr, PB, AC, DY, ptr(ws), GW, GB, 0, code, int(phases), ptr(g_scale),
                                         ctypes.addressof(adam) if adam is not None else None, stream_ptr()), "nerfhip_mlp_bwd_multi")
     return grads
+
+
+# ------------------------------------------------------------------------------- layer-by-layer path (non-default NeRF shapes)
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _rows(t):
+    """(n, c) fp32 device tensor with unit column stride (a column slice of a wider tensor is fine: row stride = ld)"""
+    if t.dim() != 2:
+        raise ValueError("expected a (n, channels) tensor")
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _off(t, col):
+    """device pointer of t[:, col:] (row-major fp32)"""
+    return ctypes.c_void_p(t.data_ptr() + 4 * col)
+
+
+class _LinearAct(torch.autograd.Function):
+    """act(cat(xs, -1) @ w.T + b) without the cat: one nerfhip_linear_fwd per input segment (the second accumulates on the first)."""
+
+    @staticmethod
+    def forward(ctx, act, dtype, w, b, *xs):
+        xs = [_rows(x.float()) for x in xs]
+        require_gpu(w, b, *xs)
+        w, b = _c(w), _c(b)
+        n, n_out, k_tot = xs[0].shape[0], w.shape[0], w.shape[1]
+        if sum(x.shape[1] for x in xs) != k_tot or any(x.shape[0] != n for x in xs) or b.numel() != n_out:
+            raise ValueError("linear: input segments %s do not match the weight %s" % ([tuple(x.shape) for x in xs], tuple(w.shape)))
+        lib = _lib.load()
+        code = mlp_dtype_code(dtype)
+        y = torch.empty(n, n_out, device=w.device, dtype=torch.float32)
+        col = 0
+        for s, x in enumerate(xs):
+            last = s == len(xs) - 1
+            check(lib.nerfhip_linear_fwd(ptr(x), x.stride(0), _off(w, col), k_tot, ptr(b) if last else None, ptr(y), n_out, n,
+                                         x.shape[1], n_out, act if last else ACT_NONE, int(s > 0), code, stream_ptr()),
+                  "nerfhip_linear_fwd")
+            col += x.shape[1]
+        ctx.cfg = (act, code)
+        ctx.save_for_backward(w, y, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        w, y, *xs = ctx.saved_tensors
+        act, code = ctx.cfg
+        lib = _lib.load()
+        gy = _c(gy.float())
+        n, n_out, k_tot = y.shape[0], w.shape[0], w.shape[1]
+        need_w, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gw = gb = None
+        gxs = []
+        if (need_w or need_b) and n > 0:
+            gw = torch.empty_like(w)
+            gb = torch.empty(n_out, device=w.device, dtype=torch.float32)
+            ws_bytes = max(lib.nerfhip_linear_bwd_weight_workspace_bytes(n, x.shape[1], n_out) for x in xs)
+            ws = torch.empty(ws_bytes, device=w.device, dtype=torch.uint8)
+        elif need_w or need_b:
+            gw, gb = torch.zeros_like(w), torch.zeros(n_out, device=w.device, dtype=torch.float32)
+        col = 0
+        for s, x in enumerate(xs):
+            if (need_w or need_b) and n > 0:
+                check(lib.nerfhip_linear_bwd_weight(ptr(gy), n_out, ptr(y), n_out, act, ptr(x), x.stride(0), _off(gw, col), k_tot,
+                                                    ptr(gb) if s == 0 else None, ptr(ws), n, x.shape[1], n_out, 0, code,
+                                                    stream_ptr()), "nerfhip_linear_bwd_weight")
+            gx = None
+            if ctx.needs_input_grad[4 + s]:
+                gx = torch.empty(n, x.shape[1], device=w.device, dtype=torch.float32)
+                check(lib.nerfhip_linear_bwd_input(ptr(gy), n_out, ptr(y), n_out, act, _off(w, col), k_tot, ptr(gx), x.shape[1], n,
+                                                   x.shape[1], n_out, 0, code, stream_ptr()), "nerfhip_linear_bwd_input")
+            gxs.append(gx)
+            col += x.shape[1]
+        return (None, None, gw if need_w else None, gb if need_b else None) + tuple(gxs)
+
+
+@device_guard
+def linear_act(xs, weight, bias, act, dtype):
+    """nn.Linear (+ activation) on the concatenation of the (n, c_i) tensors `xs` (nerf.py:59-81, 108-118), differentiable in
+    weight, bias and every segment.  act: ACT_NONE | ACT_RELU | ACT_SIGMOID."""
+    return _LinearAct.apply(int(act), dtype, weight, bias, *xs)

@@ -212,6 +212,7 @@ class GraphedTrainStep:
         self.static_batch = None
         self.static_out = None
         self.captured_lr = None
+        self.capture_fallback = None      # repr of the exception that made the one-graph capture fall back to two graphs
         # `backend` abstracts the three device facilities the stepper needs (side stream, graph capture, replay) so the
         # host logic — warm-up, capture, two-graph step with the eager collective in between, re-capture on lr change —
         # can be exercised by the world-2 gloo CPU test with a recording stand-in (tests/test_distributed_cpu.py).
@@ -258,8 +259,21 @@ class GraphedTrainStep:
         if not self._two_graphs():
             # one graph: forward, backward, [all-reduces issued from the grad-ready hooks, i.e. overlapping the rest of
             # the backward also on replay], optimizer
-            self.graph, self.static_out = self.backend.capture(lambda: self._eager(self.static_batch))
-        else:
+            try:
+                self.graph, self.static_out = self.backend.capture(lambda: self._eager(self.static_batch))
+            except Exception as e:      # noqa: BLE001
+                if self.grad_sync is None:
+                    raise
+                # a communicator whose collectives cannot be captured on this stack (every rank runs the same software, so
+                # every rank lands here together): keep the collectives outside the graphs instead
+                import warnings
+                warnings.warn("GraphedTrainStep: capturing the step with its all-reduces inside failed (%r); falling back to two "
+                              "graphs with the collectives issued eagerly in between" % (e,))
+                self.capture_fallback = repr(e)
+                self.sync_in_graph = False
+                self.graph = None
+                getattr(self.grad_sync, "_inflight", {}).clear()
+        if self._two_graphs():
             # two graphs with the collectives issued eagerly in between: the hooks must stay silent, or the fine
             # model's all-reduce would be captured into the first graph
             self._set_hooks(False)

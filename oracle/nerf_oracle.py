@@ -29,6 +29,16 @@ DIR_CH = 27
 W = 256
 
 
+def make_arch(D=8, W=W, N_freq_xyz=10, N_freq_dir=4, skips=(4,), logscale=True):
+    """A NeRF / Embedding configuration (nerf.py:5-19, 42-57).  None / make_arch() = the reference's own (train.py:34-42)."""
+    return dict(D=D, W=W, in_xyz=3 * (2 * N_freq_xyz + 1), in_dir=3 * (2 * N_freq_dir + 1), skips=tuple(skips),
+                n_freq_xyz=N_freq_xyz, n_freq_dir=N_freq_dir, logscale=logscale)
+
+
+def _arch(arch):
+    return arch if arch is not None else make_arch()
+
+
 def layer_shapes(D=8, Wd=W, in_xyz=XYZ_CH, in_dir=DIR_CH, skips=(4,)):
     """(name, out_features, in_features) in state_dict order. nerf.py:60-81."""
     shapes = []
@@ -47,14 +57,15 @@ def layer_shapes(D=8, Wd=W, in_xyz=XYZ_CH, in_dir=DIR_CH, skips=(4,)):
     return shapes
 
 
-def make_params(seed, sigma_gain=1.0, sigma_bias=0.0):
+def make_params(seed, sigma_gain=1.0, sigma_bias=0.0, arch=None):
     """Deterministic, platform-independent parameters with nn.Linear's default
     distribution U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (numpy PCG64, not torch RNG, so the
     same weights can be rebuilt on any box from the seed alone).  `sigma_gain/bias`
     rescale the density head to emulate a trained (peaky) field."""
     rng = np.random.default_rng(seed)
     p = {}
-    for name, fo, fi in layer_shapes():
+    a = _arch(arch)
+    for name, fo, fi in layer_shapes(a["D"], a["W"], a["in_xyz"], a["in_dir"], a["skips"]):
         b = 1.0 / math.sqrt(fi)
         p[name + ".weight"] = torch.from_numpy(rng.uniform(-b, b, size=(fo, fi)).astype(np.float32))
         p[name + ".bias"] = torch.from_numpy(rng.uniform(-b, b, size=(fo,)).astype(np.float32))
@@ -109,13 +120,15 @@ def _lin(p, name, h):
     return h @ p[name + ".weight"].t() + p[name + ".bias"]
 
 
-def mlp_forward(p, x, sigma_only=False, return_acts=False):
+def mlp_forward(p, x, sigma_only=False, return_acts=False, arch=None):
     """nerf.py:100-124.  x (n,90) [or (n,63) when sigma_only] -> (n,4)=[rgb,sigma] / (n,1)."""
-    enc_xyz = x[:, :XYZ_CH]
+    a = _arch(arch)
+    c_xyz, c_dir = a["in_xyz"], a["in_dir"]
+    enc_xyz = x[:, :c_xyz]
     h = enc_xyz
     acts = []
-    for i in range(8):
-        if i == 4:  # skip: [input_xyz, hidden]   nerf.py:108-109
+    for i in range(a["D"]):
+        if i in a["skips"]:  # skip: [input_xyz, hidden]   nerf.py:108-109
             h = torch.cat([enc_xyz, h], -1)
         h = torch.relu(_lin(p, f"xyz_encoding_{i+1}.0", h))
         acts.append(h)
@@ -123,7 +136,7 @@ def mlp_forward(p, x, sigma_only=False, return_acts=False):
     if sigma_only:
         return (sigma, acts) if return_acts else sigma
     feat = _lin(p, "xyz_encoding_final", h)  # no activation   nerf.py:116
-    t = torch.relu(_lin(p, "dir_encoding.0", torch.cat([feat, x[:, XYZ_CH:XYZ_CH + DIR_CH]], -1)))
+    t = torch.relu(_lin(p, "dir_encoding.0", torch.cat([feat, x[:, c_xyz:c_xyz + c_dir]], -1)))
     rgb = torch.sigmoid(_lin(p, "rgb.0", t))
     out = torch.cat([rgb, sigma], -1)  # nerf.py:122
     return (out, acts) if return_acts else out
@@ -222,30 +235,32 @@ def composite(sigmas, rgbs, z, rays_d, noise, white_back=False):
 
 
 # ----------------------------------------------------------------------------- a6/a10: render
-def _infer(p, rays, z, dir_enc, noise, white_back, weights_only, n_freq_xyz=10):
+def _infer(p, rays, z, dir_enc, noise, white_back, weights_only, arch=None):
     """`inference` closure, rendering.py:91-172 (point-chunk loop :125-133 collapsed: it is
     only a memory bound, results are chunk-invariant)."""
     B, S = z.shape
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]  # :206-207 / :231-232
-    enc = posenc(xyz.reshape(-1, 3), n_freq_xyz)
+    a = _arch(arch)
+    enc = posenc(xyz.reshape(-1, 3), a["n_freq_xyz"], a["logscale"])
     if weights_only:
-        sig = mlp_forward(p, enc, sigma_only=True).view(B, S)
+        sig = mlp_forward(p, enc, sigma_only=True, arch=a).view(B, S)
         return composite(sig, None, z, rays[:, 3:6], noise, white_back)
     x = torch.cat([enc, dir_enc.repeat_interleave(S, 0)], 1)  # :119,:129
-    o = mlp_forward(p, x).view(B, S, 4)
+    o = mlp_forward(p, x, arch=a).view(B, S, 4)
     res = composite(o[..., 3], o[..., :3], z, rays[:, 3:6], noise, white_back)
     res["raw"] = o
     return res
 
 
 def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1,
-                N_importance=0, white_back=False, test_time=False, rng=None, return_aux=False):
+                N_importance=0, white_back=False, test_time=False, rng=None, return_aux=False, arch=None):
     """rendering.py:58-244 with injected RNG.  params = [coarse_dict, fine_dict].
     rng keys: 'perturb_rand' (B,S_c) U[0,1), 'noise_coarse' (B,S_c) N(0,1),
               'u' (B,N_i) U[0,1), 'noise_fine' (B,S_f) N(0,1)."""
     rng = rng or {}
     rays = rays.float()
-    dir_enc = posenc(rays[:, 3:6], 4)  # :186 (raw, possibly non-unit d; SURVEY A.3)
+    arch = _arch(arch)
+    dir_enc = posenc(rays[:, 3:6], arch["n_freq_dir"], arch["logscale"])  # :186 (raw, possibly non-unit d; SURVEY A.3)
     z = coarse_z(rays, N_samples, use_disp, perturb, rng.get("perturb_rand"))
 
     def nz(key):
@@ -254,7 +269,7 @@ def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0, noise_std
         return rng[key] * noise_std  # :152
 
     aux = {"z_coarse": z}
-    c = _infer(params[0], rays, z, dir_enc, nz("noise_coarse"), white_back, weights_only=test_time)
+    c = _infer(params[0], rays, z, dir_enc, nz("noise_coarse"), white_back, weights_only=test_time, arch=arch)
     if test_time:  # :209-213
         result = {"opacity_coarse": c["opacity"]}
     else:
@@ -265,7 +280,7 @@ def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0, noise_std
         u = rng.get("u") if perturb != 0 else None  # det=(perturb==0)  :226
         z_new = sample_pdf(mid, c["weights"][:, 1:-1], N_importance, u=u).detach()  # :226
         zf, _ = torch.sort(torch.cat([z, z_new], -1), -1)  # :229
-        f = _infer(params[1], rays, zf, dir_enc, nz("noise_fine"), white_back, weights_only=False)
+        f = _infer(params[1], rays, zf, dir_enc, nz("noise_fine"), white_back, weights_only=False, arch=arch)
         result["rgb_fine"] = f["rgb"]
         result["depth_fine"] = f["depth"]
         result["opacity_fine"] = f["opacity"]

@@ -127,7 +127,31 @@ def _graphed_step_host_logic(rank, world):
         step1(b)
     flat1 = torch.cat([p.detach().reshape(-1) for p in sys1.parameters()])
     ok = ok and be1.captures == 2 and step1.graph_opt is None and step1.graph.replays == 2        # one graph per capture
-    return bool(ok and torch.allclose(flat1, rflat, rtol=1e-5, atol=1e-6))
+    ok = bool(ok and torch.allclose(flat1, rflat, rtol=1e-5, atol=1e-6))
+    # a stack that cannot capture the collective: the one-graph capture raises, the stepper falls back to two graphs on every
+    # rank alike and the replicas still follow the reference run
+    sys2 = _TinySystem()
+    opt2 = torch.optim.SGD(sys2.parameters(), lr=0.1)
+
+    class _NoCollectiveInGraph(_RecordingBackend):
+        def capture(self, fn, share_pool_with=None):
+            if getattr(fn, "__name__", "") == "<lambda>" and "_eager" in fn.__code__.co_names:
+                raise RuntimeError("collective not capturable")
+            return super().capture(fn, share_pool_with)
+
+    be2 = _NoCollectiveInGraph()
+    step2 = GraphedTrainStep(sys2, opt2, grad_sync=parallel.GradSync(sys2.models), warmup=2, backend=be2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, b in enumerate(batches):
+            if i == 5:
+                for grp in opt2.param_groups:
+                    grp["lr"] = 0.05
+            step2(b)
+    flat2 = torch.cat([p.detach().reshape(-1) for p in sys2.parameters()])
+    ok = ok and step2.capture_fallback is not None and step2._two_graphs() and step2.graph_opt is not None
+    return bool(ok and torch.allclose(flat2, rflat, rtol=1e-5, atol=1e-6))
 
 
 def _worker(rank, world, port, n_rays, q):
