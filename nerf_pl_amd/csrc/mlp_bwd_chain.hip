@@ -78,6 +78,17 @@ __device__ __forceinline__ void glds16b_s(const void* sbase, unsigned voff, unsi
 // ================================================================================================
 // Phase A: backward chain
 // ================================================================================================
+// W^T fragments read this many MFMA steps ahead through an explicit register ring (bf16 compute); 0: no ring, hipcc reads each
+// fragment right before its MFMA.  Measured (profiles/README.md round 3, same-call A/B, 1024 x 192): the bf16-storing variant
+// 226.9 -> 217.5 us with depth 2 (depth 1: 216-218, depth 3: 219); the e5m2-storing variant sits at its 256-register budget,
+// where the ring costs 16-48 spilled registers: 209.3 (none) / 212 (1) / 212 (2) / 222 us (3) — the two waves of a SIMD already
+// cover each other's LDS round trips there.
+#ifndef NERFHIP_CHAIN_DEPTH
+#define NERFHIP_CHAIN_DEPTH 2
+#endif
+#ifndef NERFHIP_CHAIN_DEPTH_F8
+#define NERFHIP_CHAIN_DEPTH_F8 0
+#endif
 template <int PREC>
 struct BwdStream {
     static constexpr int NW = BwdTraits<PREC>::NW;
@@ -216,11 +227,35 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
     f32x16 acc2[2];
     // compile-time loop over the tiles: guarantees static register indexing of the slab arrays (a `#pragma unroll` loop of
     // this size is not always fully unrolled, and one runtime index sends a whole 17-slab array to scratch memory)
+    // bf16: the W^T fragments travel through a ring of kChainDepth registers, read kChainDepth MFMA steps ahead of their use —
+    // also across the tiles of the layer — and a sched_barrier after every step pins that order.  (Left to itself hipcc reads each
+    // fragment into the same four registers right before its MFMA: 480 of the kernel's 716 MFMAs sit behind an
+    // `s_waitcnt lgkmcnt(0)` of their own.)
+    constexpr int NFR = NT * NKS;
+    constexpr int kChainDepth = F8 ? NERFHIP_CHAIN_DEPTH_F8 : NERFHIP_CHAIN_DEPTH;
+    [[maybe_unused]] bf16x8 afr[kChainDepth > 0 ? kChainDepth : 1];
+    [[maybe_unused]] auto frag_read = [&](auto ic) -> bf16x8 {
+        constexpr int g = G0 + decltype(ic)::value * PPF;
+        if constexpr (g % kChunkPieces == 0) st.boundary(g / kChunkPieces);
+        return *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>(piece_ptr(g));
+    };
+    if constexpr (PREC == NERFHIP_BF16 && kChainDepth > 0) {
+        bwd_static_for<0, (kChainDepth < NFR ? kChainDepth : NFR)>([&](auto jc) { afr[decltype(jc)::value] = frag_read(jc); });
+    }
     bwd_static_for<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         f32x16& acc = acc2[t & 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        if constexpr (PREC == NERFHIP_BF16 && kChainDepth > 0) {
+            bwd_static_for<0, NKS>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                constexpr int i = t * NKS + ks;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i % (kChainDepth > 0 ? kChainDepth : 1)], bslab(ks), acc, 0, 0, 0);
+                if constexpr (i + kChainDepth < NFR) afr[i % (kChainDepth > 0 ? kChainDepth : 1)] = frag_read(std::integral_constant<int, i + kChainDepth>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int g = G0 + (t * NKS + ks) * PPF;
@@ -238,6 +273,7 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bs[4 + j], acc, 0, 0, 0);
             }
+        }
         }
         if constexpr (F8 && PREC == NERFHIP_BF16) {                  // this tile's share of the INPUT section's pairs
             if constexpr (IN_PAIRS > 0) {
