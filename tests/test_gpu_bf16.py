@@ -67,7 +67,7 @@ def test_psnr_at_equal_steps_vs_fp32(dev):
     A bare `|delta| <= 0.1 dB` on one pair would therefore test the seed, not the arithmetic.  This test is the 60-second
     guard against GROSS degradation (an e4m3 dY cost 1.05 dB over three seeds): over four init/jitter seeds and the three
     post-decay checkpoints, the mean PSNR of every reduced-precision configuration is within 1.0 dB of fp32's (standard error
-    of that mean ~0.3 dB); the statistics proper are in profiles/r02_psnr_seeds_final.json (tools/psnr_seeds.py: bf16
+    of that mean ~0.3 dB); the statistics proper are in profiles/r02_psnr_seeds_final.json (tests/tools/psnr_seeds.py: bf16
     -0.27 +- 0.16 dB, bf16_f8 -0.08 +- 0.07 dB vs fp32 at 42.7 dB, four live seeds).  The noise-free half: the SAME weights
     rendered through the bf16 forward and through the fp32 forward agree to 0.1 dB."""
     from nerf_pl_amd.inference import batched_inference

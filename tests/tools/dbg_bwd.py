@@ -1,6 +1,6 @@
 """Debug: decode saved activations / gates / dY slabs of the bf16 training path and cross-check them."""
 import ctypes, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import nerf_oracle as O
 from tests.helpers import build_models
 from nerf_pl_amd import ops, _lib

@@ -1,14 +1,14 @@
 """A/B of library builds at the tensor level: run the saving forward + backward on fixed seeded inputs with the library in
 NERFHIP_LIB_PATH and dump dY slabs + gradients; `--compare a b` reports where two dumps differ.
-    NERFHIP_LIB_PATH=... python tools/dbg_chain_ab.py --dump gpurun_out/x/dump_tag.pt
-    python tools/dbg_chain_ab.py --compare gpurun_out/x/dump_a.pt gpurun_out/x/dump_b.pt"""
+    NERFHIP_LIB_PATH=... python tests/tools/dbg_chain_ab.py --dump gpurun_out/x/dump_tag.pt
+    python tests/tools/dbg_chain_ab.py --compare gpurun_out/x/dump_a.pt gpurun_out/x/dump_b.pt"""
 import argparse
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 """accuracy of the in-kernel (bf16 path) encoding vs the oracle posenc, read back from the saved activation slabs"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import nerf_oracle as O
 from nerf_pl_amd import ops
 from nerf_pl_amd.models import NeRF

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from argparse import Namespace
 from oracle import nerf_oracle as O
 from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem

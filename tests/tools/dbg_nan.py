@@ -1,5 +1,5 @@
 import torch, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import nerf_oracle as O
 from tests.helpers import build_models
 dev = torch.device('cuda:0')

@@ -1,8 +1,8 @@
 """PSNR@step gate of the reduced-precision modes on the lego-like procedural scene (tests/test_gpu_psnr_gate.py), as a tool:
 
-    python tools/psnr_gate.py --sweep "freq=6,9,14 amp=0.3,0.42"     # fp32 only, 2 seeds per scene: where does PSNR@step end?
-    python tools/psnr_gate.py --gate [--scene "freq=9 amp=0.42"] [--seeds 12] [--out gpurun_out/psnr_gate.json]
-    python tools/psnr_gate.py --sweep ... --gate --auto 31.0          # sweep, pick the scene closest to 31 dB, run the gate on it
+    python tests/tools/psnr_gate.py --sweep "freq=6,9,14 amp=0.3,0.42"     # fp32 only, 2 seeds per scene: where does PSNR@step end?
+    python tests/tools/psnr_gate.py --gate [--scene "freq=9 amp=0.42"] [--seeds 12] [--out gpurun_out/psnr_gate.json]
+    python tests/tools/psnr_gate.py --sweep ... --gate --auto 31.0          # sweep, pick the scene closest to 31 dB, run the gate on it
 
 --gate runs fp32 / bf16 / bf16_f8 from the same init, batches and draws for >= N live seeds and reports the paired
 differences to fp32 (mean, standard error).  The JSON goes to profiles/ by hand."""
@@ -15,7 +15,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import test_gpu_psnr_gate as G  # noqa: E402
 

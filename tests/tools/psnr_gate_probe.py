@@ -1,6 +1,6 @@
 """Calibration of the PSNR gate (tests/test_gpu_bf16.py): run-to-run noise of the fp32 path (different jitter seed) vs the
 gap of the reduced-precision configurations on the analytic scene; reduced-precision weights are also evaluated through the
-fp32 forward to separate training effects from evaluation noise.   python tools/psnr_gate_probe.py [--steps 1000]"""
+fp32 forward to separate training effects from evaluation noise.   python tests/tools/psnr_gate_probe.py [--steps 1000]"""
 import argparse
 import json
 import os
@@ -9,7 +9,7 @@ from argparse import Namespace
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests.helpers import analytic_scene  # noqa: E402
 

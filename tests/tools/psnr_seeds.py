@@ -2,7 +2,7 @@
 init with the compressed recipe of tests/test_gpu_bf16.py (900 steps, lr 5e-4 -> 5e-5 at 600) and report, per dtype, the
 mean and spread of the final PSNR over the seeds and the paired differences to fp32.  (Training is chaotic: single
 trajectory pairs differ by 0.1-0.4 dB already between two fp32 runs; the mean over seeds is the meaningful comparison.)
-    python tools/psnr_seeds.py [--seeds 0,1,3] [--out gpurun_out/psnr_seeds.json]"""
+    python tests/tools/psnr_seeds.py [--seeds 0,1,3] [--out gpurun_out/psnr_seeds.json]"""
 import argparse
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import test_gpu_bf16 as T  # noqa: E402
 from tests.helpers import analytic_scene  # noqa: E402

@@ -4,7 +4,7 @@ the same perturb / u draws (tests/helpers.ReplayRNG) go to the oracle (torch-CPU
 HIP bf16_f8; held-out PSNR is evaluated at the same checkpoints (README.md:75-83 recipe at reduced batch: 256 rays,
 64+64 samples, Adam 5e-4, white background, noise_std 0).  Run ON THE GPU BOX (the oracle runs on its host cores):
 
-    python tools/psnr_vs_oracle.py [--steps 250] [--every 25] [--out gpurun_out/psnr_vs_oracle.json]"""
+    python tests/tools/psnr_vs_oracle.py [--steps 250] [--every 25] [--out gpurun_out/psnr_vs_oracle.json]"""
 import argparse
 import json
 import os
@@ -14,7 +14,7 @@ from argparse import Namespace
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nerf_oracle as O  # noqa: E402  (tool, not product)
 from tests.helpers import ReplayRNG, analytic_scene  # noqa: E402
@@ -56,7 +56,7 @@ def oracle_only(a):
     r = run_oracle(a, init, draws, ckpts, rays_c, rgbs_c, rays_vc, rgb_vc, S, N, B)
     with open(a.oracle_json, "w") as fh:
         json.dump({"key": "steps=%d,every=%d,rays=%d" % (a.steps, a.every, B), "psnr": r["psnr"], "loss": r["loss"],
-                   "what": "CPU oracle (oracle/nerf_oracle.py, torch-CPU fp32) trained by tools/psnr_vs_oracle.py --oracle-only"}, fh, indent=1)
+                   "what": "CPU oracle (oracle/nerf_oracle.py, torch-CPU fp32) trained by tests/tools/psnr_vs_oracle.py --oracle-only"}, fh, indent=1)
 
 
 def main():

@@ -6,7 +6,7 @@ a fixed "teacher" radiance field (a NeRF with a sharpened density head) rendered
 provides the ground-truth colour of every training / held-out ray.  The question answered is the one
 BASELINE.json asks of the bf16 configuration: does PSNR at equal steps stay within 0.1 dB of fp32?
 
-    python tools/psnr_vs_step.py [--steps 2000] [--oracle-steps 20] [--out gpurun_out/psnr_r01.json]
+    python tests/tools/psnr_vs_step.py [--steps 2000] [--oracle-steps 20] [--out gpurun_out/psnr_r01.json]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ from argparse import Namespace
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import nerf_oracle as O  # noqa: E402  (tool, not product)

@@ -3,7 +3,7 @@ import cProfile, pstats, sys, os, io
 from argparse import Namespace
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import nerf_oracle as O
+import _synth  # tools/_synth.py
 from nerf_pl_amd.system import NeRFSystem
 dev = torch.device("cuda:0")
 hp = Namespace(N_samples=64, N_importance=128, use_disp=False, perturb=1.0, noise_std=0.0, chunk=1024 * 32, loss_type="mse",
@@ -13,7 +13,7 @@ for m in system.models:
     m.mlp_dtype = "bf16"
 system = system.to(dev)
 (opt,), _ = system.configure_optimizers()
-batch = {"rays": O.make_rays(1, 1024, "blender").to(dev), "rgbs": torch.rand(1024, 3, device=dev)}
+batch = {"rays": _synth.make_rays(1, 1024, dev), "rgbs": torch.rand(1024, 3, device=dev)}
 def step():
     out = system.training_step(batch, 0)
     opt.zero_grad(set_to_none=True)

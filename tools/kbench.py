@@ -12,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import nerf_oracle as O  # noqa: E402
+import _synth  # noqa: E402  (tools/_synth.py: seeded synthetic rays / weights)
 from nerf_pl_amd import ops  # noqa: E402
 from nerf_pl_amd.models import NeRF  # noqa: E402
 
@@ -32,11 +32,8 @@ def timed(fn, reps):
 
 def merged(a, dev, m_fine):
     B = a.rays
-    rays = O.make_rays(1, B, "blender").to(dev)
-    m_coarse = NeRF()
-    m_coarse.load_state_dict(O.make_params(100, 4.0, 0.2))
-    m_coarse.mlp_dtype = a.dtype
-    m_coarse = m_coarse.to(dev)
+    rays = _synth.make_rays(1, B, dev)
+    m_coarse = _synth.make_model(100, dev, a.dtype)
     entries = []
     for m, S in ((m_fine, a.samples), (m_coarse, 64)):
         z = torch.sort(2 + 4 * torch.rand(B, S, device=dev), -1)[0]
@@ -66,14 +63,11 @@ def main():
                     help="library built with -DNERFHIP_CLOCK_PROBE=1, --dtype bf16_f8: shader clock and cycles of the saving forward")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    m = NeRF()
-    m.load_state_dict(O.make_params(101, 4.0, 0.2))
-    m.mlp_dtype = a.dtype
-    m = m.to(dev)
+    m = _synth.make_model(101, dev, a.dtype)
     B, S = a.rays, a.samples
     if a.merged:
         return merged(a, dev, m)
-    rays = O.make_rays(1, B, "blender").to(dev)
+    rays = _synth.make_rays(1, B, dev)
     z = torch.sort(2 + 4 * torch.rand(B, S, device=dev), -1)[0]
     packed = m.packed_weights(a.dtype)
     pb = m.packed_weights_bwd(a.dtype)

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import nerf_oracle as O  # noqa: E402
+import _synth  # noqa: E402  (tools/_synth.py: seeded synthetic rays / poses)
 from nerf_pl_amd import ops, rays as R  # noqa: E402
 
 
@@ -28,7 +28,7 @@ def main():
     dev = torch.device("cuda:0")
     B, Sc, Ni = 32768, 64, 128
     Sf = Sc + Ni
-    rays = O.make_rays(1, B, "blender").to(dev)
+    rays = _synth.make_rays(1, B, dev)
     rows = []
 
     def rec(name, us, nbytes, note):
@@ -58,7 +58,7 @@ def main():
     wts, opac, rgb, dep = ops.composite(raw_g, zf, rays, None, 0.0, True)
     g = torch.randn_like(rgb)
     rec("composite_bwd S=192 (g_rgb only)", timed(lambda: torch.autograd.grad(rgb, raw_g, g, retain_graph=True)), B * (Sf * 20 + 12 + Sf * 16), "%d rays" % B)
-    poses = torch.stack([O.make_pose(i) for i in range(100)]).to(dev)
+    poses = torch.stack([_synth.make_pose(i) for i in range(100)]).to(dev)
     ids = torch.randint(0, 100 * 800 * 800, (1 << 20,), device=dev)
     rec("gen_rays (pixel ids -> rays)", timed(lambda: R.gen_rays(poses, 800, 800, 1111.1, 2.0, 6.0, pixel_ids=ids)), (1 << 20) * 40, "1,048,576 rays")
     out = os.path.join(ROOT, "gpurun_out", "kbench_hbm.json")

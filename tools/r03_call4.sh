@@ -25,7 +25,7 @@ for l in open('gpurun_out/r03d/kbench.txt'):
 print({k:min(v) for k,v in t.items()})
 if min(t.get('xbf8',[1e9])) < 0.97*min(t.get('saddr',[0])):
     env=dict(os.environ, NERFHIP_LIB_PATH=os.getcwd()+'/nerf_pl_amd/variants/libnerfhip_xbf8.so')
-    subprocess.run("timeout 420 python tools/psnr_gate.py --gate --dtypes bf16_f8 --out gpurun_out/r03d/psnr_gate_xbf8.json > gpurun_out/r03d/psnr_gate_xbf8.log 2>&1; grep -E 'mean|stderr' gpurun_out/r03d/psnr_gate_xbf8.log | tail -8", shell=True, env=env)
+    subprocess.run("timeout 420 python tests/tools/psnr_gate.py --gate --dtypes bf16_f8 --out gpurun_out/r03d/psnr_gate_xbf8.json > gpurun_out/r03d/psnr_gate_xbf8.log 2>&1; grep -E 'mean|stderr' gpurun_out/r03d/psnr_gate_xbf8.log | tail -8", shell=True, env=env)
 else:
     print("xbf8 not faster: PSNR gate skipped")
 PY

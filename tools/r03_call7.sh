@@ -1,11 +1,11 @@
 mkdir -p gpurun_out/r03i
 OUT=gpurun_out/r03i
 # tensor-level A/B: chain looped (main) vs the round-2 chain (old): bf16 / fp32 storage must be bit-identical
-NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_old.so python tools/dbg_chain_ab.py --dump $OUT/dump_old.pt | tail -1
-python tools/dbg_chain_ab.py --dump $OUT/dump_main.pt | tail -1
-NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_gate128.so python tools/dbg_chain_ab.py --dump $OUT/dump_gate128.pt | tail -1
-echo "=== old vs main"; python tools/dbg_chain_ab.py --compare $OUT/dump_old.pt $OUT/dump_main.pt 2>&1 | tee $OUT/compare_old_main.txt
-echo "=== main vs gate128"; python tools/dbg_chain_ab.py --compare $OUT/dump_main.pt $OUT/dump_gate128.pt 2>&1 | grep -E "acts|flat" | tee $OUT/compare_main_gate128.txt
+NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_old.so python tests/tools/dbg_chain_ab.py --dump $OUT/dump_old.pt | tail -1
+python tests/tools/dbg_chain_ab.py --dump $OUT/dump_main.pt | tail -1
+NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_gate128.so python tests/tools/dbg_chain_ab.py --dump $OUT/dump_gate128.pt | tail -1
+echo "=== old vs main"; python tests/tools/dbg_chain_ab.py --compare $OUT/dump_old.pt $OUT/dump_main.pt 2>&1 | tee $OUT/compare_old_main.txt
+echo "=== main vs gate128"; python tests/tools/dbg_chain_ab.py --compare $OUT/dump_main.pt $OUT/dump_gate128.pt 2>&1 | grep -E "acts|flat" | tee $OUT/compare_main_gate128.txt
 rm -f $OUT/dump_*.pt
 for rep in 1 2; do
 for v in main old gate128 prio; do

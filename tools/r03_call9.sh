@@ -1,8 +1,8 @@
 mkdir -p gpurun_out/r03k
 OUT=gpurun_out/r03k
-NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_old.so python tools/dbg_chain_ab.py --dump $OUT/dump_old.pt | tail -1
-python tools/dbg_chain_ab.py --dump $OUT/dump_main.pt | tail -1
-echo "=== old vs main"; python tools/dbg_chain_ab.py --compare $OUT/dump_old.pt $OUT/dump_main.pt 2>&1 | grep -E "flat" | tee $OUT/compare_old_main.txt
+NERFHIP_LIB_PATH=$PWD/nerf_pl_amd/variants/libnerfhip_old.so python tests/tools/dbg_chain_ab.py --dump $OUT/dump_old.pt | tail -1
+python tests/tools/dbg_chain_ab.py --dump $OUT/dump_main.pt | tail -1
+echo "=== old vs main"; python tests/tools/dbg_chain_ab.py --compare $OUT/dump_old.pt $OUT/dump_main.pt 2>&1 | grep -E "flat" | tee $OUT/compare_old_main.txt
 rm -f $OUT/dump_*.pt
 for rep in 1 2; do
 for v in main old; do

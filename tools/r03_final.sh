@@ -22,9 +22,9 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 done
-NERFHIP_LIB_PATH=$REPO/nerf_pl_amd/variants/libnerfhip_d0.so python tools/dbg_chain_ab.py --dump $OUT/dump_d0.pt 2>/dev/null | tail -1
-python tools/dbg_chain_ab.py --dump $OUT/dump_main.pt 2>/dev/null | tail -1
-python tools/dbg_chain_ab.py --compare $OUT/dump_d0.pt $OUT/dump_main.pt > $OUT/chain_ring_tensor_ab.txt 2>&1; rm -f $OUT/dump_*.pt
+NERFHIP_LIB_PATH=$REPO/nerf_pl_amd/variants/libnerfhip_d0.so python tests/tools/dbg_chain_ab.py --dump $OUT/dump_d0.pt 2>/dev/null | tail -1
+python tests/tools/dbg_chain_ab.py --dump $OUT/dump_main.pt 2>/dev/null | tail -1
+python tests/tools/dbg_chain_ab.py --compare $OUT/dump_d0.pt $OUT/dump_main.pt > $OUT/chain_ring_tensor_ab.txt 2>&1; rm -f $OUT/dump_*.pt
 python -m pytest tests -q -m gpu --deselect tests/test_gpu_psnr_gate.py 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5 | tee $OUT/pytest.txt
-[ -n "${SKIP_PSNR:-}" ] || timeout 420 python tools/psnr_gate.py --gate --out $OUT/psnr_gate.json > $OUT/psnr_gate.log 2>&1; grep -E '"mean"|"stderr"|fp32"' $OUT/psnr_gate.log | tail -8
+[ -n "${SKIP_PSNR:-}" ] || timeout 420 python tests/tools/psnr_gate.py --gate --out $OUT/psnr_gate.json > $OUT/psnr_gate.log 2>&1; grep -E '"mean"|"stderr"|fp32"' $OUT/psnr_gate.log | tail -8
 ls $OUT
