@@ -122,3 +122,26 @@ def test_header_is_plain_c_and_links(lib, tmp_path):
     hip = "/opt/rocm/lib"
     subprocess.run(["gcc", str(tmp_path / "use_all.o"), "-o", str(tmp_path / "use_all"), "-L", libdir, "-lnerfhip",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + hip, "-L", hip, "-lamdhip64"], check=True)
+
+
+def test_linear_entry_points_validate_arguments_without_a_gpu(lib):
+    """The layer-by-layer path's C entry points (non-default NeRF shapes): argument validation returns NERFHIP_E_BADARG before
+    anything is launched, and the weight-gradient workspace follows the documented split plan (whole 128 x 128/256 tiles per
+    split + one bias row per split)."""
+    null = None
+    # n_in < 1, ld < n_in, unknown activation, unknown dtype: refused (-1) with null pointers never dereferenced
+    assert lib.nerfhip_linear_fwd(null, 8, null, 8, null, null, 8, 16, 0, 8, 0, 0, 0, null) == -1
+    assert lib.nerfhip_linear_fwd(null, 4, null, 8, null, null, 8, 16, 8, 8, 0, 0, 0, null) == -1
+    assert lib.nerfhip_linear_fwd(null, 8, null, 8, null, null, 8, 16, 8, 8, 3, 0, 0, null) == -1
+    assert lib.nerfhip_linear_fwd(null, 8, null, 8, null, null, 8, 16, 8, 8, 0, 0, 9, null) == -1
+    assert lib.nerfhip_linear_fwd(null, 8, null, 8, null, null, 8, 16, 8, 8, 0, 0, 0, null) == -1      # null tensors, n > 0
+    assert lib.nerfhip_linear_fwd(null, 8, null, 8, null, null, 8, 0, 8, 8, 0, 0, 0, null) == 0        # n == 0: nothing to do
+    assert lib.nerfhip_linear_bwd_input(null, 8, null, 8, 1, null, 8, null, 8, 16, 8, 8, 0, 0, null) == -1   # ReLU needs y
+    assert lib.nerfhip_linear_bwd_weight(null, 8, null, 8, 0, null, 8, null, 8, null, null, 16, 8, 8, 0, 0, null) == -1
+    ws = lib.nerfhip_linear_bwd_weight_workspace_bytes
+    assert ws(0, 8, 8) == 0 and ws(16, 0, 8) == 0
+    one = ws(100, 63, 256)            # 1 split: 256 x 128 tile floats + 256 bias floats
+    assert one == (256 * 128 + 256) * 4
+    big = ws(196608, 256, 256)        # 2 x 1 tiles of 128 x 256: 512 two-tile workgroup equivalents => 256 splits of 768 points
+    assert big == 256 * (256 * 256 + 256) * 4
+    assert ws(196608, 319, 256) == 128 * (256 * 512 + 256) * 4      # two 256-column tiles per row of tiles: half the splits
