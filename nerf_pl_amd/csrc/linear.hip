@@ -85,7 +85,7 @@ template <bool ROWC, int ROWS, int NT> struct Units {
     }
 };
 
-template <bool ROWC, int ROWS, int NT>
+template <bool ROWC, int ROWS, int NT, bool VEC>
 __device__ __forceinline__ void fetch(const Operand& O, int64_t r0, int64_t k0, int64_t kend, float (&v)[Units<ROWC, ROWS, NT>::UPT][4]) {
     using U = Units<ROWC, ROWS, NT>;
     const int t = (int)threadIdx.x;
@@ -103,7 +103,7 @@ __device__ __forceinline__ void fetch(const Operand& O, int64_t r0, int64_t k0, 
         const bool ok = ROWC ? (k0 + k < kend) : (r0 + r < O.rows);
         float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (ok && lim > 0) {
-            if (O.vec) {
+            if (VEC || O.vec) {
                 const float4 q = *reinterpret_cast<const float4*>(base + off);
                 x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
                 if (ybase) {
@@ -186,8 +186,11 @@ template <bool ROWC, int ROWS> __device__ __forceinline__ float frag_f32(const f
 // panel, i.e. the activations, is then read once for up to 256 output features).  ws != nullptr (weight gradient): the raw tile
 // goes to ws[blockIdx.z][i][j] (whole tiles) and the row sums of A (the bias gradient) to gb_ws[blockIdx.z][i]; the reduce
 // kernel finishes the job.  `tj` = number of j tiles; blockIdx.x = i tile * tj + j tile.
-template <bool F32, bool AROWC, bool BROWC, int TJ>
-__global__ __launch_bounds__(TJ * 2) void linear_gemm_kernel(Operand A, Operand B, int64_t K, int64_t k_per_split, float* __restrict__ C,
+// VEC: both operands take 16-byte loads (the kernel without the scalar-load path).  Its bf16 instantiations are compiled for 4
+// (TJ = 256: two 8-wave workgroups per CU, 13-17 spilled registers) / 3 (TJ = 128: three 4-wave workgroups) waves per SIMD: the
+// kernel is bound by the bytes of register-staged loads in flight per CU, and the second workgroup buys 20 % (profiles/README.md).
+template <bool F32, bool AROWC, bool BROWC, int TJ, bool VEC>
+__global__ __launch_bounds__(TJ * 2, (!F32 && VEC) ? (TJ == 256 ? 4 : 3) : 1) void linear_gemm_kernel(Operand A, Operand B, int64_t K, int64_t k_per_split, float* __restrict__ C,
                                                              int64_t ldc, int64_t I, int64_t J, const float* __restrict__ bias, int act,
                                                              int accumulate, float* __restrict__ ws, float* __restrict__ gb_ws, int tj) {
     constexpr int TI = kTileI, NT = TJ * 2;
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(TJ * 2) void linear_gemm_kernel(Operand A, Operand 
 #pragma unroll
     for (int u = 0; u < kDepth; ++u)
         if (u < nst) {
-            fetch<AROWC, TI, NT>(A, i0, kbeg + u * kStage, kend, va[u]);
-            fetch<BROWC, TJ, NT>(B, j0, kbeg + u * kStage, kend, vb[u]);
+            fetch<AROWC, TI, NT, VEC>(A, i0, kbeg + u * kStage, kend, va[u]);
+            fetch<BROWC, TJ, NT, VEC>(B, j0, kbeg + u * kStage, kend, vb[u]);
         }
     for (int64_t st = 0; st < nst; st += kDepth) {
 #pragma unroll
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(TJ * 2) void linear_gemm_kernel(Operand A, Operand 
             stash<F32, BROWC, TJ, NT>(Bs, vb[u]);
             __syncthreads();
             if (st + u + kDepth < nst) {
-                fetch<AROWC, TI, NT>(A, i0, kbeg + (st + u + kDepth) * kStage, kend, va[u]);
-                fetch<BROWC, TJ, NT>(B, j0, kbeg + (st + u + kDepth) * kStage, kend, vb[u]);
+                fetch<AROWC, TI, NT, VEC>(A, i0, kbeg + (st + u + kDepth) * kStage, kend, va[u]);
+                fetch<BROWC, TJ, NT, VEC>(B, j0, kbeg + (st + u + kDepth) * kStage, kend, vb[u]);
             }
             if constexpr (F32) {
 #pragma unroll
@@ -364,20 +367,20 @@ static int vec_ok(const float* p, int64_t s, const float* y, int64_t ys) {
 
 // grid.x = (i tiles) x (j tiles), grid.z = splits
 template <bool AROWC, bool BROWC, typename... Args>
-static int launch_gemm(bool f32, int TJ, int64_t ti, int64_t tj, int splits, hipStream_t stream, Args... args) {
+static int launch_gemm(bool f32, int TJ, int64_t ti, int64_t tj, int splits, hipStream_t stream, const Operand& A, const Operand& B,
+                       Args... args) {
     if (ti * tj > 0x7fffffff) return NERFHIP_E_BADARG;
     const dim3 grid((unsigned)(ti * tj), 1, (unsigned)splits);
+    const bool vec = A.vec && B.vec;          // both operands 16-byte loadable: the kernel without the scalar-load path
+#define NH_LIN_LAUNCH(F, T, V) hipLaunchKernelGGL((linear_gemm_kernel<F, AROWC, BROWC, T, V>), grid, dim3(2 * T), 0, stream, A, B, args..., (int)tj)
     if (TJ == 256) {
-        if (f32)
-            hipLaunchKernelGGL((linear_gemm_kernel<true, AROWC, BROWC, 256>), grid, dim3(512), 0, stream, args..., (int)tj);
-        else
-            hipLaunchKernelGGL((linear_gemm_kernel<false, AROWC, BROWC, 256>), grid, dim3(512), 0, stream, args..., (int)tj);
+        if (f32) { if (vec) NH_LIN_LAUNCH(true, 256, true); else NH_LIN_LAUNCH(true, 256, false); }
+        else     { if (vec) NH_LIN_LAUNCH(false, 256, true); else NH_LIN_LAUNCH(false, 256, false); }
     } else {
-        if (f32)
-            hipLaunchKernelGGL((linear_gemm_kernel<true, AROWC, BROWC, 128>), grid, dim3(256), 0, stream, args..., (int)tj);
-        else
-            hipLaunchKernelGGL((linear_gemm_kernel<false, AROWC, BROWC, 128>), grid, dim3(256), 0, stream, args..., (int)tj);
+        if (f32) { if (vec) NH_LIN_LAUNCH(true, 128, true); else NH_LIN_LAUNCH(true, 128, false); }
+        else     { if (vec) NH_LIN_LAUNCH(false, 128, true); else NH_LIN_LAUNCH(false, 128, false); }
     }
+#undef NH_LIN_LAUNCH
     return nerfhip_launch_status();
 }
 
