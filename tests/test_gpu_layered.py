@@ -212,3 +212,40 @@ def test_sigma_grid_non_default_vs_oracle(dev):
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5), (got - ref).abs().max()
     with pytest.raises(ValueError):
         sigma_grid(m, N, (-1, 1), (-1, 1), (-1, 1))
+
+
+def test_nerfsystem_with_a_non_default_shape_graphed_equals_eager(dev):
+    """NeRFSystem whose models / embeddings were swapped for a non-default configuration (what a subclass of the reference's
+    system would do): training_step falls back to the modular graph (render_rays layer by layer -> MSELoss), FlatAdam updates
+    the 2 x (2 D + 8) tensors, and the whole step replays as a hipGraph with the same losses and weights as eager issue."""
+    from argparse import Namespace
+    from nerf_pl_amd.models import Embedding, NeRF
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    arch = O.make_arch(D=3, W=64, N_freq_xyz=5, N_freq_dir=2, skips=(1,))
+    gen = torch.Generator().manual_seed(2)
+    batches = [{"rays": O.make_rays(20 + i, 96, "blender").to(dev), "rgbs": torch.rand(96, 3, generator=gen).to(dev)} for i in range(7)]
+    finals, losses = [], []
+    for graphed in (False, True):
+        hp = Namespace(N_samples=16, N_importance=16, use_disp=False, perturb=0.0, noise_std=0.0, chunk=1024, loss_type="mse",
+                       lr=1e-3, weight_decay=0, decay_step=[100], decay_gamma=0.5, white_back=True)
+        system = NeRFSystem(hp)
+        for name, seed in (("nerf_coarse", 31), ("nerf_fine", 32)):
+            m = NeRF(D=arch["D"], W=arch["W"], in_channels_xyz=arch["in_xyz"], in_channels_dir=arch["in_dir"], skips=list(arch["skips"]))
+            m.load_state_dict(O.make_params(seed, 4.0, 0.2, arch=arch))
+            m.mlp_dtype = "fp32"
+            setattr(system, name, m)
+        system.models = [system.nerf_coarse, system.nerf_fine]
+        system.embedding_xyz, system.embedding_dir = Embedding(3, 5), Embedding(3, 2)
+        system.embeddings = [system.embedding_xyz, system.embedding_dir]
+        system = system.to(dev)
+        assert not system._fused_step_ok(batches[0]["rays"])
+        (opt,), _ = system.configure_optimizers()
+        stepper = GraphedTrainStep(system, opt, warmup=2 if graphed else 10 ** 9)
+        ls = [stepper(b)["loss"].item() for b in batches]
+        assert (stepper.graph is not None) == graphed
+        losses.append(ls)
+        finals.append({k: v.detach().cpu().clone() for k, v in system.state_dict().items()})
+    assert losses[0] == pytest.approx(losses[1], rel=1e-5), (losses[0], losses[1])
+    assert losses[0][-1] < losses[0][0]
+    for k in finals[0]:
+        assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-5, atol=1e-7), k
