@@ -12,7 +12,7 @@ python bench.py --dtype fp32 --steps 20 --warmup 5 --no-cpu-baseline --no-extras
 python bench.py --mode render --no-cpu-baseline > $OUT/bench_render.json 2>/dev/null
 python bench.py --mode eval --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_eval.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-extras --modular-step > $OUT/bench_modular_step.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-extras --no-fuse-adam > $OUT/bench_no_fuse_adam.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extras --fuse-adam > $OUT/bench_fuse_adam.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-extras --force-dist --sync-in-graph 1 > $OUT/bench_rccl_world1_one_graph.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-extras --force-dist --sync-in-graph 0 > $OUT/bench_rccl_world1_two_graphs.json 2>/dev/null
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
