@@ -1,6 +1,6 @@
 """bench.py — rays/sec of the NeRF hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16_f8|bf16|fp32] [--mode train|render]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|bf16_f8|fp32] [--mode train|render|eval]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16_f8", choices=["bf16", "bf16_f8", "fp32"],
-                    help="bf16_f8 (default): bf16 MFMA forward + dX chain, saved activations/dY stored as block-scaled e4m3 for the "
-                         "dW GEMM; bf16: the same with bf16 storage; fp32: exact-fp32 MFMA (parity configuration)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16_f8", "fp32"],
+                    help="bf16 (default; the arithmetic BASELINE.json configs[2] names): bf16 MFMA everywhere, saved tensors in bf16; "
+                         "bf16_f8: the same forward + dX chain, saved activations/dY stored as block-scaled 8-bit floats and the dW GEMM on "
+                         "the MX-scaled fp8 MFMA (reported beside the headline as f8_dw_ms_per_step); fp32: exact-fp32 MFMA (parity)")
     ap.add_argument("--mode", default="train", choices=["train", "render", "eval"])
     ap.add_argument("--image-rays", type=int, default=640000, help="--mode eval: rays per image (800x800), sharded over ranks")
     ap.add_argument("--rays", type=int, default=1024)
@@ -62,7 +63,10 @@ def parse():
                     help="N=1: apply Adam inside the dW-reduce kernel instead of as its own launch (one launch fewer; measured 0-15 us "
                          "SLOWER per step in six same-call pairs on four boxes, so off by default)")
     ap.add_argument("--no-fuse-adam", action="store_true", help="(the default since round 3; accepted for older command lines)")
-    ap.add_argument("--no-extras", action="store_true", help="train mode: skip the eval / render / bf16-storage side measurements")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="train mode: skip the side measurements (eval / render / fp8-dW variant / configs[1] and configs[3] steps / PMC passes)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not take HBM counters in-run (rocprofv3 --pmc passes of this build's kernels)")
+    ap.add_argument("--pmc-launch", action="store_true", help=argparse.SUPPRESS)   # child mode of the PMC passes: launch the kernels, print nothing
     ap.add_argument("--force-dist", action="store_true",
                     help="N=1: initialise the RCCL process group and route gradients through GradSync anyway (A/B of the N>1 step)")
     ap.add_argument("--sync-in-graph", type=int, default=None, choices=[0, 1],
@@ -201,6 +205,123 @@ def synth_store(seed, dev, n_img=20, hw=200):
     poses = torch.stack([right, upv, -fwd, c], -1).float().contiguous()   # (n_img, 3, 4) = [R | t]
     rgbs = torch.rand(n_img * hw * hw, 3, generator=g)
     return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.3, 2.0, 6.0)
+
+
+def synth_store_ndc(seed, dev, n_img=20, hw=200):
+    """The same in the reference's forward-facing LLFF layout (llff.py:236-253): cameras near the origin looking down -z with
+    small rotations, rays converted to NDC (near plane 1.0), bounds 0..1, non-unit directions."""
+    from nerf_pl_amd.rays import RayStore
+    g = torch.Generator().manual_seed(seed)
+    w = 0.1 * torch.randn(n_img, 3, generator=g)                          # small axis-angle rotations
+    K = torch.zeros(n_img, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    R = torch.matrix_exp(K)
+    t = 0.3 * torch.randn(n_img, 3, 1, generator=g)
+    poses = torch.cat([R, t], -1).float().contiguous()
+    rgbs = torch.rand(n_img * hw * hw, 3, generator=g)
+    return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.35, 0.0, 1.0, use_ndc=True, ndc_near_plane=1.0)
+
+
+# ---- HBM counters of THIS run's kernels (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes with --kernel-trace only,
+# as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled: gfx950 tallies 64 B per 128-B request of the wide reads these kernels
+# make).  The passes re-run this file in `--pmc-launch` mode: every MLP kernel of the step twice on resident buffers. ----
+def pmc_launch(a):
+    from nerf_pl_amd import ops
+    from nerf_pl_amd.models import NeRF
+    dev = torch.device("cuda", 0)
+    B, S, N = a.rays, a.n_samples, a.n_importance
+    models = []
+    for sd in (100, 101):
+        m = NeRF()
+        m.load_state_dict(synth_params(sd, 4.0, 0.2))
+        m.mlp_dtype = a.dtype
+        models.append(m.to(dev))
+    rays = synth_rays(1234, B).to(dev)
+    with torch.no_grad():
+        z = ops.sample_coarse_z(rays, S, False, 0.0)
+        zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
+        pk = models[1].packed_weights(a.dtype)
+        entries = []
+        for model, zz in ((models[1], zf), (models[0], z)):
+            acts = ops.alloc_acts(zz.numel(), a.dtype, dev)
+            pf, pb = model.packed_weights_train(a.dtype)
+            pf, pb = pf.clone(), pb.clone()
+            for _ in range(2):
+                raw = ops.mlp_fwd_rays(rays, zz, pf, False, a.dtype, save=acts)
+            entries.append((torch.randn_like(raw), raw, pb, acts))
+        ws = {}
+        for _ in range(2):
+            ops.mlp_bwd_multi(entries, a.dtype, workspace=ws)           # chain x 2, merged dW, merged reduce
+            ops.mlp_fwd_rays(rays, zf, pk, False, a.dtype)               # the inference forward (north star)
+    torch.cuda.synchronize()
+
+
+def pmc_collect(a, note):
+    """{traffic key: {'hbm_bytes_per_launch': ...}} of this build's MLP kernels at this run's sizes, or {} (and why, in note)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        note["traffic_note"] = "rocprofv3 not on PATH: " + note.get("traffic_note", "")
+        return {}
+    B, S, N = a.rays, a.n_samples, a.n_importance
+    P_f, P_c = B * (S + N), B * S
+    grid = lambda P: (P + 255) // 256 * 512                              # bf16 kernels: 256 points = 8 waves per workgroup
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="nerfhip_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for C in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, C)
+            cmd = ["rocprofv3", "--pmc", C, "--kernel-trace", "-f", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-launch", "--dtype", a.dtype, "--rays", str(B), "--n-samples", str(S), "--n-importance", str(N)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
+            fs = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                note["traffic_note"] = "in-run rocprofv3 --pmc %s pass failed (rc %s): %s" % (C, r.returncode, note.get("traffic_note", ""))
+                return {}
+            per = collections.defaultdict(float)
+            csv.field_size_limit(1 << 30)
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] == C and "mlp_" in row["Kernel_Name"]:
+                    name = row["Kernel_Name"].replace("void ", "").replace("nerfhip::", "").split("(")[0]
+                    per[(name, int(row["Grid_Size"]), row["Dispatch_Id"])] += float(row["Counter_Value"])
+            agg = collections.defaultdict(list)
+            for (name, g, _), v in per.items():
+                agg[(name, g)].append(v)
+            for k, v in agg.items():
+                vals.setdefault(k, {})[C] = sum(v) / len(v)
+    except Exception as e:  # noqa: BLE001 - counters are an extra, never fatal
+        note["traffic_note"] = "in-run PMC passes failed (%s: %s): %s" % (type(e).__name__, e, note.get("traffic_note", ""))
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    db = {}
+    for (name, g), cs in vals.items():
+        if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+            continue
+        base = name.split("<")[0]
+        targs = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",") if "<" in name else []
+        P = P_f if g == grid(P_f) else (P_c if g == grid(P_c) else None)
+        if base == "mlp_fwd_kernel" and P is not None and targs[2] != "true":
+            key = "mlp_fwd_kernel" if targs[3] in ("0", "false") else "mlp_fwd_kernel<save>"
+        elif base == "mlp_bwd_chain_kernel" and P is not None:
+            key = "mlp_bwd_chain_kernel"
+        elif base in ("mlp_bwd_dw_kernel", "mlp_bwd_dw_f8_kernel"):
+            key, P = "mlp_bwd_dw_kernel<merged>", P_f + P_c
+        elif base == "mlp_bwd_reduce_kernel":
+            key, P = "mlp_bwd_reduce_kernel<merged>", P_f + P_c
+        else:
+            continue
+        db["%s|%s|%d" % (key, a.dtype, P)] = {"hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+                                               "FETCH_SIZE_KB": round(cs["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(cs["WRITE_SIZE"], 1)}
+    if db:
+        note["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken IN THIS RUN on this box (bench.py --pmc-launch: every MLP "
+                                "kernel of the step twice; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE KB, the guide's gfx950 correction)")
+    return db
 
 
 def load_traffic_db(note):
@@ -346,6 +467,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
 
 def main():
     a = parse()
+    if a.pmc_launch:
+        return pmc_launch(a)
     self_launch(a)
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block on the
     # first communicator) are diverted to stderr for the whole run; the result goes to the saved descriptor.
@@ -391,7 +514,7 @@ def main():
                    loss_type="mse", lr=5e-4, weight_decay=0, decay_step=[2, 4, 8], decay_gamma=0.5, white_back=True,
                    optimizer="adam", lr_scheduler="steplr")
 
-    def build_system(dtype):
+    def build_system(dtype, hp=hp):
         system = NeRFSystem(hp)
         # random-init weights of the named architecture (identical on every rank = DDP replicas), density head
         # scaled so that opacity is non-trivial
@@ -427,12 +550,17 @@ def main():
 
     # The training step (fwd, loss, bwd, [all-reduce], Adam: ~40 launches) is replayed as ONE hipGraph after 3 eager
     # steps; same work per step, ~15 us of host time instead of ~1.5 ms.  Falls back to eager issue if capture fails.
-    def make_stepper(system_, opt_, sync_):
-        # fresh batches are drawn INSIDE the graph (RayStore.sample with the default generator: randint + gen_rays + gather are
-        # captured, torch's graph-safe Philox state advances per replay): no per-step copies into static buffers
+    def make_stepper(system_, opt_, sync_, store_=None):
+        # fresh batches are drawn INSIDE the graph: RayStore.sample draws the pixel ids from the default generator's Philox stream,
+        # generates their rays, gathers their colours AND makes the step's four render_rays draws in ONE captured launch; the
+        # generator state lives on the device and advances per replay (nerf_pl_amd/draws.py): no per-step copies into static buffers
         in_graph = not a.fixed_batch
+        store_ = store_ if store_ is not None else store
+        hp_ = system_.hp
         kw = {} if a.sync_in_graph is None else {"sync_in_graph": bool(a.sync_in_graph)}
-        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=(lambda: store.sample(B)) if in_graph else None, **kw)
+        from nerf_pl_amd.system import _HipGraphBackend
+        src = (lambda: store_.sample(B, step_draws=(hp_.N_samples, hp_.N_importance, hp_.perturb, hp_.noise_std))) if in_graph else None
+        st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=src, backend=_HipGraphBackend(keep_graph=True), **kw)
               if not a.no_graph else None}
 
         def eager(batch):
@@ -500,11 +628,60 @@ def main():
             dt_ = float(t.item())
         return dt_
 
+    def side_steps():
+        """Extras of the default line, measured AFTER the headline's timed region: the fp8-dW variant of the same step (its own
+        process: a dedicated run, not a second system squeezed into this one), BASELINE configs[1] (fp32, 64+64) and configs[3]
+        (NDC rays, noise_std=1, black background, 64+64) training steps."""
+        import subprocess
+        ex = {}
+        step_flops_pt = FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW
+        if a.dtype == "bf16":
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "bf16_f8", "--steps", "15", "--warmup", "6", "--no-extras",
+                   "--no-cpu-baseline", "--rays", str(B), "--n-samples", str(S), "--n-importance", str(N)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+                line = json.loads(r.stdout.strip().splitlines()[-1])
+                ex["f8_dw_ms_per_step"] = line["ms_per_step"]
+                ex["f8_dw_rays_per_s"] = line["value"]
+                ex["f8_dw_dtype"] = line["dtype"]
+                ex["f8_dw_step_frac_mfma_of_bf16_peak"] = line.get("step_frac_mfma")
+                ex["f8_dw_mlp_kernels_us_per_step"] = line.get("mlp_kernels_us_per_step")
+                ex["roofline_kernels_f8"] = line.get("roofline_kernels")
+                ex["f8_dw_note"] = ("the same step with the saved activations / dY stored as block-scaled 8-bit floats and the dW GEMM on "
+                                    "the MX-scaled fp8 MFMA (licensed by tests/test_gpu_psnr_gate.py), measured by its own "
+                                    "`bench.py --dtype bf16_f8` process after the headline; NOT the BASELINE-named arithmetic")
+            except Exception as e:  # noqa: BLE001 - an extra, never fatal
+                ex["f8_dw_note"] = "fp8-dW side run failed: %s: %s" % (type(e).__name__, e)
+        # configs[1]: fp32 (the 1e-4 parity arithmetic), 64 + 64 samples
+        hp1 = Namespace(**dict(vars(hp), N_importance=64))
+        sys1, opt1 = build_system("fp32", hp1)
+        st1, _ = make_stepper(sys1, opt1, None)
+        t1 = timed(st1, 5, 8) / 8
+        ex["fp32_c1_ms_per_step"] = round(t1 * 1e3, 4)
+        ex["fp32_c1_frac_mfma"] = round(step_flops_pt * B * (2 * S + 64) / t1 / 1e12 / PEAK_TFLOPS["fp32"], 4)
+        ex["fp32_c1_note"] = "configs[1]: %d rays x (%d+64) samples, exact-fp32 MFMA MLP, full training step; frac of the 157.3 TFLOP/s fp32 MFMA peak" % (B, S)
+        del sys1, opt1, st1
+        # configs[3]: LLFF-style NDC rays (non-unit directions), noise_std = 1 (rendering.py:152 noise path), black background, 64 + 64
+        hp3 = Namespace(**dict(vars(hp), N_importance=64, noise_std=1.0, white_back=False))
+        sys3, opt3 = build_system(a.dtype, hp3)
+        st3, _ = make_stepper(sys3, opt3, None, synth_store_ndc(777, dev))
+        t3 = timed(st3, 5, 15) / 15
+        ex["ndc_c3_ms_per_step"] = round(t3 * 1e3, 4)
+        ex["ndc_c3_frac_mfma"] = round(step_flops_pt * B * (2 * S + 64) / t3 / 1e12 / PEAK_TFLOPS[a.dtype], 4)
+        ex["ndc_c3_note"] = ("configs[3] per GPU: %d NDC rays x (%d+64) samples, noise_std=1, white_back=False, %s, full training step "
+                             "(the 8-GPU half of configs[3] is the --gpus N line)" % (B, S, DTYPE_LABEL[a.dtype]))
+        del sys3, opt3, st3
+        return ex
+
     dt = timed(step, max(a.warmup, 5) if a.mode == "train" else a.warmup, a.steps)     # >= 5: 3 eager + capture + 1 replay
 
     if rank == 0:
         extra = {}
         traffic_db = load_traffic_db(extra)
+        if a.mode == "train" and world == 1 and not a.no_extras and not a.no_pmc and a.dtype != "fp32":
+            live = pmc_collect(a, extra)                     # this box's own counters replace the stamped file's
+            if live:
+                traffic_db = dict(traffic_db, **live)
         if a.mode == "train":                                  # forward-only rate of the same workload
             for _ in range(5):
                 render_step()
@@ -576,13 +753,14 @@ def main():
             # whole-step MFMA fraction: algorithmic FLOPs of the step (GEMMs only) over the step time
             step_flops = (FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW) * B * (2 * S + N)
             extra["step_frac_mfma"] = round(step_flops / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
-            if a.dtype == "bf16_f8" and world == 1 and not a.no_extras:
-                # the same step with bf16 storage of the saved tensors (no fp8 anywhere), for reference
-                sys2, opt2 = build_system("bf16")
-                step2, _ = make_stepper(sys2, opt2, None)
-                dt2 = timed(step2, 6, 15)
-                extra["bf16_storage_ms_per_step"] = round(dt2 / 15 * 1e3, 4)
-                del sys2, opt2, step2
+            g_ = state["graphed"]
+            if g_ is not None and g_.graph is not None:
+                from nerf_pl_amd.system import graph_node_count
+                # nodes of the replayed hipGraph = launches per step (hipGraphGetNodes on the captured graph)
+                extra["launches_per_step"] = graph_node_count(g_.graph)
+            extra["non_mlp_us"] = round(dt / a.steps * 1e6 - mix_us, 1)      # step - the six MLP kernels replayed together
+            if world == 1 and not a.no_extras:
+                extra.update(side_steps())
         else:
             extra["roofline"] = ns
 
@@ -608,7 +786,7 @@ def main():
                        "mlp_dtype": a.dtype,
                        "rays_per_gpu": (a.image_rays // world if a.mode == "eval" else B), "N_samples": S, "N_importance": N,
                        "batches": ("one resident batch replayed" if (a.fixed_batch or a.mode != "train") else
-                                   "fresh RayStore.sample(%d) per step inside the timed loop (pixel ids -> rays on the GPU%s)"
+                                   "fresh RayStore.sample(%d) per step inside the timed loop (pixel ids + rays + the step's draws in one launch on the GPU%s)"
                                    % (B, ", captured in the step's hipGraph" if not a.no_graph else "")),
                        "issue": ("hipGraph replay of the whole step" if (a.mode == "train" and state["graphed"] is not None
                                                                          and state["graphed"].graph is not None)
@@ -616,7 +794,8 @@ def main():
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if dist is not None and a.mode == "train" else ""),
                        "step_form": (None if a.mode != "train" else
                                      "modular autograd graph (render_rays -> MSELoss), separate Adam launch" if a.modular_step else
-                                     "fused node: composite+loss+composite-backward per pass, one pack / dW / reduce launch for both models"
+                                     "fused node: batch + draws in one launch, coarse depths in the MLP prologue, composite+loss-gradient+composite-backward "
+                                     "(+ fine depths | + loss) per pass, one pack / dW / reduce launch for both models"
                                      + (", Adam applied inside the reduce kernel" if system.fuse_adam else ", separate Adam launch")),
                        "rccl_nranks": rccl_nranks,
                        "capture_fallback": (getattr(state["graphed"], "capture_fallback", None) if a.mode == "train" else None),

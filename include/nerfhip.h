@@ -125,6 +125,22 @@ int nerfhip_composite_train(const float* raw, const float* z, const float* rays,
                             int white_back, const float* target, float grad_scale, float* weights, float* rgb, float* depth,
                             float* opacity, float* g_raw, int64_t B, int S, nerfhip_stream_t stream);
 
+/* The coarse pass of a training step (rendering.py:143-172 + :223-229): nerfhip_composite_train and, for the same ray in the same
+ * wave, nerfhip_fine_z on its weights (u / u_stride / N_i / eps / z_fine as there) — the weights travel from the quadrature to the
+ * inverse-CDF sampling through LDS (`weights` may be NULL).  Bit-identical to the two launches.                            */
+int nerfhip_composite_train_fine_z(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                                   int white_back, const float* target, float grad_scale, float* weights, float* rgb, float* depth,
+                                   float* opacity, float* g_raw, int64_t B, int S, const float* u, int64_t u_stride, int N_i,
+                                   float eps, float* z_fine, nerfhip_stream_t stream);
+/* The last pass of a training step: nerfhip_composite_train + the loss values of nerfhip_mse_psnr (losses.py:9-14,
+ * metrics.py:4-13) — out3 = [loss, psnr, mse] over this pass's rgb as the fine image and rgb_coarse (B,3; NULL when this pass is
+ * the only one) as the coarse image, reduced by the last workgroup to finish in nerfhip_mse_psnr's own order (same bits).
+ * ticket: one zero-initialised DEVICE word owned by the caller; the launch leaves it at zero.                              */
+int nerfhip_composite_train_loss(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                                 int white_back, const float* target, float grad_scale, float* weights, float* rgb, float* depth,
+                                 float* opacity, float* g_raw, int64_t B, int S, const float* rgb_coarse, float* out3,
+                                 uint32_t* ticket, nerfhip_stream_t stream);
+
 /* ---- a3/a4. NeRF MLP  (models/nerf.py:42-124; D=8 W=256 skips=[4] in 63/27) -------------
  * Parameters are repacked once per weight update into the MFMA A-fragment stream the
  * kernel consumes (layout: DESIGN.md §3).  weights_host[i]/biases_host[i] are HOST arrays of
@@ -151,6 +167,13 @@ int nerfhip_mlp_fwd_embedded(const float* x, int64_t x_stride, int64_t n, const 
  * rays (B,8), z (B,S) -> out (B,S,4) | (B,S) when sigma_only.                               */
 int nerfhip_mlp_fwd_rays(const float* rays, const float* z, int64_t B, int S, const void* packed, float* out,
                          int sigma_only, int dtype, void* save_acts, nerfhip_stream_t stream);
+
+/* The same for the COARSE pass with its depths formed in the kernel's prologue (rendering.py:183-204 = nerfhip_sample_coarse_z,
+ * then :206-207): z (B,S) is an OUTPUT here — every point's depth is computed from its ray's bounds (and perturb_rand (B,S), the
+ * caller's U[0,1) draw, when perturb > 0), used, and written for the compositing that follows.  Same bits as the two launches. */
+int nerfhip_mlp_fwd_rays_coarse(const float* rays, const float* perturb_rand, float* z, int64_t B, int S, int use_disp,
+                                float perturb, const void* packed, float* out, int sigma_only, int dtype, void* save_acts,
+                                nerfhip_stream_t stream);
 
 /* ---- backward of the MLP (autograd mirror of nerf.py:100-124 under train.py:103-117) -----------
  * Two hand-written phases: the register-resident chain in reverse with W^T streamed
@@ -283,6 +306,46 @@ int nerfhip_gen_rays(const float* c2w, const int64_t* pixel_ids, int64_t first_p
 int nerfhip_sample_batch(const float* c2w, const int64_t* pixel_ids, const float* rgbs_all, int64_t n, int H, int W,
                          double focal, float near, float far, int use_ndc, float ndc_near_plane, float* rays, float* rgbs,
                          nerfhip_stream_t stream);
+
+/* ---- the random draws of a training step, as torch's generator would make them  (rendering.py:203,152,39,152; the
+ * DataLoader's batch of train.py:89-94) ----
+ * ONE launch producing up to 6 tensors from the Philox4x32-10 stream that torch.rand / torch.randn / torch.randint on the GPU
+ * consume: draw i is what the i-th of those torch calls would return for a generator at (seed, offset), bit for bit, and
+ * *increment_host is what the calls together advance the generator's offset by (the caller then sets the generator to
+ * offset + increment: same seed => same training run, whichever path draws).  max_blocks = multiProcessorCount *
+ * (maxThreadsPerMultiProcessor / 256) of the device (ATen's launch cap; 2048 on MI355X).
+ *   kind UNIFORM: out = numel floats of torch.rand; NORMAL: torch.randn; RANDINT: numel int64 of torch.randint(0, range)
+ *   (range < 2^32).  A draw with out == NULL (and no batch) is one nobody reads — the reference always draws its noise tensors,
+ *   also when noise_std == 0 (rendering.py:152): the stream moves past it exactly as the torch call would, nothing is computed.
+ * batch_host (NULL ok): draws_host[0] must then be RANDINT over the store's pixel ids; the drawn ids are turned into the
+ * training batch in the same launch — rays (numel,8) and rgbs (numel,3) exactly as nerfhip_sample_batch — and draws_host[0].out
+ * may be NULL (the ids themselves are then not stored).
+ * state (NULL ok): a DEVICE buffer of 4 x uint64 {seed, offset, arrival ticket (0), -}.  When given, seed / offset are read
+ * from it instead of the arguments and its offset is advanced by the increment at the end of the launch, so that hipGraph
+ * replays of one captured call keep walking the stream.                                                                  */
+#define NERFHIP_DRAW_UNIFORM 0
+#define NERFHIP_DRAW_NORMAL 1
+#define NERFHIP_DRAW_RANDINT 2
+typedef struct nerfhip_draw {
+    int kind;
+    int64_t numel;
+    void* out;
+    uint64_t range;
+} nerfhip_draw;
+typedef struct nerfhip_ray_batch {
+    const float* c2w;       /* (n_images,3,4) poses */
+    const float* rgbs_all;  /* (n_images*H*W,3) pixel colours, or NULL (then rgbs NULL too) */
+    float* rays;            /* (numel,8) out, 16-byte aligned */
+    float* rgbs;            /* (numel,3) out */
+    int H, W;
+    double focal;
+    float near, far;
+    int use_ndc;
+    float ndc_near_plane;
+} nerfhip_ray_batch;
+uint64_t nerfhip_torch_draw_increment(int64_t numel, int max_blocks);
+int nerfhip_torch_draws(const nerfhip_draw* draws_host, int n_draws, const nerfhip_ray_batch* batch_host, uint64_t seed,
+                        uint64_t offset, uint64_t* state, int max_blocks, uint64_t* increment_host, nerfhip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,15 @@ SIGNATURES = {
                                              ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
     "nerfhip_composite_train": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
                                 _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
+    "nerfhip_composite_train_fine_z": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p, _i64, _int, _f32, _c_void_p, _c_void_p],
+    "nerfhip_composite_train_loss": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
+                                     _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "nerfhip_mlp_fwd_rays_coarse": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _f32, _c_void_p, _c_void_p, _int, _int,
+                                    _c_void_p, _c_void_p],
+    "nerfhip_torch_draw_increment": [_i64, _int],
+    "nerfhip_torch_draws": [_c_void_p, _int, _c_void_p, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _int,
+                            ctypes.POINTER(ctypes.c_uint64), _c_void_p],
     "nerfhip_mlp_dw_workspace_bytes_multi": [ctypes.POINTER(_i64), _int, _int],
     "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
@@ -91,7 +100,20 @@ class AdamFused(ctypes.Structure):
                 ("grad_flat", _c_void_p * 2), ("state", _c_void_p), ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32),
                 ("weight_decay", _f32)]
 
-_RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_mlp_packed_bytes": ctypes.c_size_t,
+class Draw(ctypes.Structure):
+    """include/nerfhip.h: nerfhip_draw"""
+    _fields_ = [("kind", _int), ("numel", _i64), ("out", _c_void_p), ("range", ctypes.c_uint64)]
+
+
+class RayBatch(ctypes.Structure):
+    """include/nerfhip.h: nerfhip_ray_batch"""
+    _fields_ = [("c2w", _c_void_p), ("rgbs_all", _c_void_p), ("rays", _c_void_p), ("rgbs", _c_void_p), ("H", _int), ("W", _int),
+                ("focal", ctypes.c_double), ("near", _f32), ("far", _f32), ("use_ndc", _int), ("ndc_near_plane", _f32)]
+
+
+DRAW_UNIFORM, DRAW_NORMAL, DRAW_RANDINT = 0, 1, 2
+
+_RESTYPES = {"nerfhip_error_string": ctypes.c_char_p, "nerfhip_torch_draw_increment": ctypes.c_uint64, "nerfhip_mlp_packed_bytes": ctypes.c_size_t,
              "nerfhip_mlp_act_bytes": ctypes.c_size_t, "nerfhip_mlp_packed_bwd_bytes": ctypes.c_size_t,
              "nerfhip_mlp_dy_bytes": ctypes.c_size_t, "nerfhip_mlp_dw_workspace_bytes": ctypes.c_size_t,
              "nerfhip_mlp_dw_workspace_bytes_multi": ctypes.c_size_t,

@@ -4,7 +4,8 @@
 // S*4 + 20 B out per ray, every byte touched once, loads coalesced along the sample axis.
 // Transmittance is a wave-wide exclusive prefix product (fp64, rounded per element like
 // torch-CPU cumprod) chained across 64-sample chunks.
-#include "common.h"
+#include "loss_math.h"
+#include "sampling_wave.h"
 
 namespace nerfhip {
 
@@ -205,17 +206,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 // the backward of composite_bwd_kernel<4> for exactly that upstream gradient, in ONE launch — three launches (forward, loss
 // gradient scaling, backward) and an HBM round trip of rgb fewer per pass.  Every value is formed by the same expressions in
 // the same order as in the separate kernels, so g_raw is bit-identical to composite_fwd -> mse_psnr -> composite_bwd.
-__global__ __launch_bounds__(256) void composite_train_kernel(const float* __restrict__ raw, const float* __restrict__ z,
-                                                              const float* __restrict__ rays, const float* __restrict__ noise,
-                                                              float noise_std, int white_back, const float* __restrict__ target,
-                                                              float gscale, float* __restrict__ weights, float* __restrict__ rgb,
-                                                              float* __restrict__ depth, float* __restrict__ opacity,
-                                                              float* __restrict__ g_raw, int64_t B, int S) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    if (r >= B) return;
-    float* T_s = lds + (size_t)wave * S;       // transmittance T_i
+// One ray per wave.  T_s: S floats of LDS (transmittance between the sweeps); w_s (NULL ok): S floats of LDS that receive the
+// ray's weights for a consumer in the same kernel (the fine-pass depth assembly below) instead of / besides `weights` in HBM.
+__device__ __forceinline__ void composite_train_wave(const float* __restrict__ raw, const float* __restrict__ z,
+                                                     const float* __restrict__ rays, const float* __restrict__ noise,
+                                                     float noise_std, int white_back, const float* __restrict__ target,
+                                                     float gscale, float* __restrict__ weights, float* __restrict__ rgb,
+                                                     float* __restrict__ depth, float* __restrict__ opacity,
+                                                     float* __restrict__ g_raw, int64_t r, int S, float* T_s, float* w_s, int lane) {
     const float dnorm = ray_dnorm(rays, r);
     const float* zr = z + r * S;
     // ---- forward sweep (composite_fwd_kernel<4>) ----
@@ -242,6 +240,7 @@ __global__ __launch_bounds__(256) void composite_train_kernel(const float* __res
         const float w = valid ? nh_mul(t.alpha, T) : 0.0f;
         if (valid) {
             if (weights) weights[r * S + i] = w;
+            if (w_s) w_s[i] = w;
             T_s[i] = T;
         }
         acc_o += w;
@@ -305,6 +304,85 @@ __global__ __launch_bounds__(256) void composite_train_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256) void composite_train_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                              const float* __restrict__ rays, const float* __restrict__ noise,
+                                                              float noise_std, int white_back, const float* __restrict__ target,
+                                                              float gscale, float* __restrict__ weights, float* __restrict__ rgb,
+                                                              float* __restrict__ depth, float* __restrict__ opacity,
+                                                              float* __restrict__ g_raw, int64_t B, int S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    composite_train_wave(raw, z, rays, noise, noise_std, white_back, target, gscale, weights, rgb, depth, opacity, g_raw, r, S,
+                         lds + (size_t)wave * S, nullptr, lane);
+}
+
+// The coarse pass of a training step: composite_train_kernel + the fine-pass depth assembly of rendering.py:223-229
+// (fine_z_kernel of sampling.hip: z_mid, sample_pdf on weights[:, 1:-1], sort(cat)) for the same ray in the same wave — the
+// weights go from the quadrature to the inverse-CDF sampling through LDS and need not exist in HBM at all (`weights` NULL).
+// Same expressions in the same order as the two kernels: bit-identical z_fine.
+__global__ __launch_bounds__(256) void composite_train_fine_z_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                     const float* __restrict__ rays, const float* __restrict__ noise,
+                                                                     float noise_std, int white_back, const float* __restrict__ target,
+                                                                     float gscale, float* __restrict__ weights, float* __restrict__ rgb,
+                                                                     float* __restrict__ depth, float* __restrict__ opacity,
+                                                                     float* __restrict__ g_raw, int64_t B, int S,
+                                                                     const float* __restrict__ u, int64_t u_stride, int N, float eps,
+                                                                     float* __restrict__ z_fine) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    const int S4 = (S + 3) & ~3;
+    float* T_s = lds + (size_t)wave * (2 * S4 + fine_z_lds_floats(S, N));
+    float* w_s = T_s + S4;
+    composite_train_wave(raw, z, rays, noise, noise_std, white_back, target, gscale, weights, rgb, depth, opacity, g_raw, r, S, T_s,
+                         w_s, lane);
+    __builtin_amdgcn_wave_barrier();
+    fine_z_wave(w_s + S4, z + r * S, [&](int j) { return w_s[1 + j]; }, u ? u + r * u_stride : nullptr, S, N, eps,
+                z_fine + r * (S + N), nullptr, nullptr, nullptr, lane);
+}
+
+// The fine (last) pass of a training step: composite_train_kernel + the step's loss values (mse_psnr_kernel of loss.hip without
+// its gradient outputs): every workgroup announces its rays' finished colours with an arrival ticket, and the last one to
+// arrive reduces the two images against the target in mse_psnr_kernel's own order (loss_math.h) — out3 = [loss, psnr, mse],
+// bit-identical to the separate launch.  `ticket` is a zero-initialised device word the kernel leaves at zero.
+__global__ __launch_bounds__(256) void composite_train_loss_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                   const float* __restrict__ rays, const float* __restrict__ noise,
+                                                                   float noise_std, int white_back, const float* __restrict__ target,
+                                                                   float gscale, float* __restrict__ weights, float* rgb,
+                                                                   float* __restrict__ depth, float* __restrict__ opacity,
+                                                                   float* __restrict__ g_raw, int64_t B, int S,
+                                                                   const float* __restrict__ rgb_coarse, float* __restrict__ out3,
+                                                                   unsigned* __restrict__ ticket) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[2][16];
+    __shared__ unsigned last_s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r < B)
+        composite_train_wave(raw, z, rays, noise, noise_std, white_back, target, gscale, weights, rgb, depth, opacity, g_raw, r, S,
+                             lds + (size_t)wave * S, nullptr, lane);
+    __threadfence();                 // this wave's rgb row is visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(ticket, 1u);
+        last_s = (prev == gridDim.x - 1) ? 1u : 0u;
+        if (prev == gridDim.x - 1) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    // the fine image written by the OTHER workgroups of this launch: device-scope loads (the L2 of this XCD is not theirs)
+    const float* rgb_f = rgb;
+    auto fresh = [&](int64_t i) { return __hip_atomic_load(rgb_f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (rgb_coarse)
+        mse_psnr_block<4>([&](int64_t i) { return rgb_coarse[i]; }, fresh, true, target, 3 * B, out3, nullptr, nullptr, red);
+    else                            // N_importance == 0: this pass IS the coarse pass, the loss has one term
+        mse_psnr_block<4>(fresh, [&](int64_t i) { return 0.0f; }, false, target, 3 * B, out3, nullptr, nullptr, red);
+}
+
 }  // namespace nerfhip
 
 extern "C" int nerfhip_composite_train(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
@@ -359,5 +437,38 @@ extern "C" int nerfhip_composite_bwd(const float* raw, int raw_ch, const float* 
     else
         hipLaunchKernelGGL(nerfhip::composite_bwd_kernel<1>, grid, block, lds, (hipStream_t)stream, raw, z, rays,
                            noise, noise_std, white_back, g_rgb, g_depth, g_opacity, g_weights, g_raw, B, S);
+    return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_composite_train_fine_z(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                                              int white_back, const float* target, float grad_scale, float* weights, float* rgb,
+                                              float* depth, float* opacity, float* g_raw, int64_t B, int S, const float* u,
+                                              int64_t u_stride, int N_i, float eps, float* z_fine, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 3 && S <= 2048 && N_i >= 1);
+    const int S4 = (S + 3) & ~3, N4 = (N_i + 3) & ~3;
+    const size_t per_wave = (size_t)(2 * S4 + 3 * S4 + N4 + ((S + 1 + 3) & ~3) + N4) * sizeof(float);
+    NERFHIP_CHECK_ARG(4 * per_wave <= 65536);
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(raw && z && rays && target && rgb && depth && opacity && g_raw && z_fine);
+    if ((((uintptr_t)raw) | ((uintptr_t)g_raw)) & 15) return NERFHIP_E_ALIGN;
+    if (noise_std == 0.0f) noise = nullptr;
+    hipLaunchKernelGGL(nerfhip::composite_train_fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 4 * per_wave,
+                       (hipStream_t)stream, raw, z, rays, noise, noise_std, white_back, target, grad_scale, weights, rgb, depth,
+                       opacity, g_raw, B, S, u, u_stride, N_i, eps, z_fine);
+    return nerfhip_launch_status();
+}
+
+extern "C" int nerfhip_composite_train_loss(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
+                                            int white_back, const float* target, float grad_scale, float* weights, float* rgb,
+                                            float* depth, float* opacity, float* g_raw, int64_t B, int S, const float* rgb_coarse,
+                                            float* out3, uint32_t* ticket, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 1 && S <= 2048);
+    if (B == 0) return 0;
+    NERFHIP_CHECK_ARG(raw && z && rays && target && rgb && depth && opacity && g_raw && out3 && ticket);
+    if ((((uintptr_t)raw) | ((uintptr_t)g_raw)) & 15) return NERFHIP_E_ALIGN;
+    if (noise_std == 0.0f) noise = nullptr;
+    hipLaunchKernelGGL(nerfhip::composite_train_loss_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)4 * S * sizeof(float),
+                       (hipStream_t)stream, raw, z, rays, noise, noise_std, white_back, target, grad_scale, weights, rgb, depth,
+                       opacity, g_raw, B, S, rgb_coarse, out3, ticket);
     return nerfhip_launch_status();
 }

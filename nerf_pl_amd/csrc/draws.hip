@@ -1,0 +1,220 @@
+// The random draws of one training step in ONE launch, bit for bit what torch's own generators produce.
+//
+// The reference draws four tensors inside every render_rays call — rand(B,S) jitter (rendering.py:203), randn(B,S) noise (:152),
+// rand(B,N_i) importance uniforms (:39), randn(B,S+N_i) noise (:152) — and its DataLoader picks the batch's pixels
+// (train.py:89-94, blender.py:81-84).  On the GPU each of these is a ~5 us launch (plus the fill of the generator's graph-safe
+// offset when captured): six of the training step's graph nodes.  This kernel produces all of them from the SAME Philox
+// stream torch.rand / torch.randn / torch.randint would consume — same seed, same offsets, same values — so a step that uses
+// it sees exactly the draws of a step that calls torch, and the caller advances torch's generator by the returned increment.
+//
+// What is replicated (ATen native/cuda/DistributionTemplates.h on ROCm: hiprand == rocrand's Philox4x32-10):
+//   * launch shape: 256-thread blocks, grid = min(max_blocks, ceil(numel / 256)), max_blocks = CUs * (max threads per CU / 256);
+//   * thread idx owns Philox subsequence idx at offset `offset` (counter = [offset/4 lo, hi, idx lo, hi], key = seed) and, per
+//     round of its grid-stride loop, ONE 4-word block whose word ii belongs to element idx + ii * 256 * grid;
+//   * the generator advances by ((numel - 1) / (256 * grid * 4) + 1) * 4 per draw;
+//   * uniform:  u = 2^-32 + x * 2^-32  in (0, 1], the value 1 mapped to 0 (ATen's bound reversal);
+//   * normal:   Box-Muller on word pairs, (x,y) -> r sin, r cos with r = sqrt(-2 log(2^-32 + x 2^-32)), angle 2 pi (2^-32 + y 2^-32)
+//               through the hardware sin / cos (rocrand's __sincosf);
+//   * randint:  (x mod range) for range < 2^32, as int64.
+// A randint draw can carry a ray batch: the drawn pixel ids then go straight into ray generation and the colour gather
+// (rays.hip: nerfhip_sample_batch) without a round trip through HBM.
+//
+// Generator state.  Eager calls pass (seed, offset) by value.  A hipGraph replay must see a NEW offset every time, so a
+// captured call reads (seed, offset) from a 4 x u64 device buffer `state` = {seed, offset, arrival ticket, -} and the last
+// workgroup to finish advances the offset by the call's total increment (every workgroup read the old one first).
+#include "rays_math.h"
+
+namespace nerfhip {
+
+constexpr int kDrawMax = 6;
+struct RayBatch {
+    const float* c2w;
+    const float* rgbs_all;
+    float* rays;
+    float* rgbs;
+    int H, W;
+    float focal, near, far;
+    int use_ndc;
+    float ndc_plane, sx, sy;
+};
+struct DrawTable {
+    void* out[kDrawMax];
+    int64_t numel[kDrawMax];
+    unsigned long long rel[kDrawMax];      // Philox offset of the draw relative to the call's offset
+    unsigned long long range[kDrawMax];
+    int block0[kDrawMax + 1];              // first workgroup of each draw
+    int kind[kDrawMax];
+    int count;
+    int batch_draw;                        // index of the randint draw that feeds `batch` (-1: none)
+    unsigned long long total;              // the call's total increment
+    RayBatch batch;
+};
+
+// Philox4x32-10 (Random123 constants), one 4-word block
+__device__ __forceinline__ uint4 philox_block(uint4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// The float transforms are compiled like the library torch links (hipcc's default contraction), not like the rest of this
+// library (common.h: contraction off): `c + y * c` in the Box-Muller angle is one fma there.
+__device__ __forceinline__ float philox_uniform(unsigned x) {
+#pragma clang fp contract(fast)
+    const float v = 2.3283064e-10f + ((float)x * 2.3283064e-10f);        // rocrand uniform_distribution: (0, 1]
+    const float value = v * 1.0f + 0.0f;                                  // ATen uniform_: rand * (to - from) + from
+    return value == 1.0f ? 0.0f : value;                                  // ... and its bound reversal: [0, 1)
+}
+__device__ __forceinline__ void philox_normal2(unsigned x, unsigned y, float& a, float& b) {
+#pragma clang fp contract(fast)
+    const float u = 2.3283064e-10f + ((float)x * 2.3283064e-10f);
+    const float v = 1.46291807e-09f + ((float)y * 1.46291807e-09f);       // rocrand box_muller: 2 pi 2^-32 (y + 1)
+    const float s = sqrtf(-2.0f * logf(u));
+    float sn, cs;
+    __sincosf(v, &sn, &cs);
+    a = (sn * s) * 1.0f + 0.0f;                                           // ATen normal_: rand * std + mean
+    b = (cs * s) * 1.0f + 0.0f;
+}
+
+__global__ __launch_bounds__(256) void philox_draws_kernel(DrawTable T, unsigned long long seed_v, unsigned long long offset_v,
+                                                           unsigned long long* __restrict__ state) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < kDrawMax; ++k) s += (k < T.count && (int)blockIdx.x >= T.block0[k]) ? 1 : 0;
+    const unsigned long long seed = state ? state[0] : seed_v;
+    const unsigned long long off = (state ? state[1] : offset_v) + T.rel[s];
+    const int grid = T.block0[s + 1] - T.block0[s];
+    const int64_t G = (int64_t)256 * grid;
+    const int64_t idx = (int64_t)((int)blockIdx.x - T.block0[s]) * 256 + threadIdx.x;
+    const int64_t numel = T.numel[s];
+    const int64_t rounded = numel > 0 ? ((numel - 1) / (G * 4) + 1) * G * 4 : 0;
+    const int kind = T.kind[s];
+    const unsigned long long range = T.range[s];
+    // rocrand_init(seed, subsequence = idx, offset): counter = [offset / 4, idx]
+    const unsigned long long c0 = off >> 2;
+    uint4 ctr = make_uint4((unsigned)c0, (unsigned)(c0 >> 32), (unsigned)idx, (unsigned)((unsigned long long)idx >> 32));
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int64_t li0 = idx; li0 < rounded; li0 += G * 4) {
+        const uint4 r = philox_block(ctr, k0, k1);
+        ctr.x += 1u;                                                       // next4(): bump the 128-bit counter
+        if (ctr.x == 0u) { ctr.y += 1u; if (ctr.y == 0u) { ctr.z += 1u; if (ctr.z == 0u) ctr.w += 1u; } }
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kind == 0) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) f[ii] = philox_uniform(w[ii]);
+        } else if (kind == 1) {
+            philox_normal2(w[0], w[1], f[0], f[1]);
+            philox_normal2(w[2], w[3], f[2], f[3]);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int64_t li = li0 + G * ii;
+            if (li >= numel) continue;
+            if (kind == 2) {
+                const int64_t id = (int64_t)((unsigned long long)w[ii] % range);     // ATen uniform_int_from_to, 32-bit path
+                if (T.out[s]) reinterpret_cast<int64_t*>(T.out[s])[li] = id;
+                if (s == T.batch_draw) {
+                    const RayBatch& b = T.batch;
+                    if (b.rgbs) {
+                        b.rgbs[3 * li] = b.rgbs_all[3 * id];
+                        b.rgbs[3 * li + 1] = b.rgbs_all[3 * id + 1];
+                        b.rgbs[3 * li + 2] = b.rgbs_all[3 * id + 2];
+                    }
+                    gen_ray(b.c2w, id, b.H, b.W, b.focal, b.near, b.far, b.use_ndc, b.ndc_plane, b.sx, b.sy, b.rays + li * 8);
+                }
+            } else {
+                reinterpret_cast<float*>(T.out[s])[li] = f[ii];
+            }
+        }
+    }
+    if (state) {       // arrival ticket: the last workgroup advances the offset (every workgroup read the old one above)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long prev = atomicAdd(state + 2, 1ull);
+            if (prev == (unsigned long long)gridDim.x - 1ull) {
+                state[2] = 0ull;
+                state[1] = (off - T.rel[s]) + T.total;
+            }
+        }
+    }
+}
+
+static inline int draw_grid(int64_t numel, int max_blocks) {
+    const int64_t need = (numel + 255) / 256;
+    return (int)(need < (int64_t)max_blocks ? need : (int64_t)max_blocks);
+}
+static inline unsigned long long draw_increment(int64_t numel, int max_blocks) {
+    if (numel <= 0) return 0ull;                                           // ATen returns before touching the generator
+    const int64_t per_round = (int64_t)256 * draw_grid(numel, max_blocks) * 4;
+    return (unsigned long long)(((numel - 1) / per_round + 1) * 4);
+}
+
+}  // namespace nerfhip
+
+extern "C" uint64_t nerfhip_torch_draw_increment(int64_t numel, int max_blocks) {
+    if (max_blocks < 1) return 0;
+    return (uint64_t)nerfhip::draw_increment(numel, max_blocks);
+}
+
+extern "C" int nerfhip_torch_draws(const nerfhip_draw* draws_host, int n_draws, const nerfhip_ray_batch* batch_host, uint64_t seed,
+                                   uint64_t offset, uint64_t* state, int max_blocks, uint64_t* increment_host,
+                                   nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(draws_host && n_draws >= 1 && n_draws <= nerfhip::kDrawMax && max_blocks >= 1);
+    NERFHIP_CHECK_ARG(state || (offset & 3) == 0);
+    nerfhip::DrawTable T{};
+    T.count = 0;
+    T.batch_draw = -1;
+    int blocks = 0;
+    unsigned long long rel = 0;
+    for (int i = 0; i < n_draws; ++i) {
+        const nerfhip_draw& d = draws_host[i];
+        NERFHIP_CHECK_ARG(d.numel >= 0 && d.kind >= NERFHIP_DRAW_UNIFORM && d.kind <= NERFHIP_DRAW_RANDINT);
+        const bool with_batch = (batch_host && i == 0);
+        if (with_batch) NERFHIP_CHECK_ARG(d.kind == NERFHIP_DRAW_RANDINT);
+        if (d.numel == 0) continue;
+        if (d.kind == NERFHIP_DRAW_RANDINT) NERFHIP_CHECK_ARG(d.range >= 1 && d.range < (1ull << 32));
+        if (!d.out && !with_batch) {           // a draw nobody reads: the stream moves past it, nothing is launched for it
+            rel += nerfhip::draw_increment(d.numel, max_blocks);
+            continue;
+        }
+        const int k = T.count++;
+        T.out[k] = d.out;
+        T.numel[k] = d.numel;
+        T.rel[k] = rel;
+        T.range[k] = d.kind == NERFHIP_DRAW_RANDINT ? d.range : 1ull;
+        T.kind[k] = d.kind;
+        T.block0[k] = blocks;
+        blocks += nerfhip::draw_grid(d.numel, max_blocks);
+        rel += nerfhip::draw_increment(d.numel, max_blocks);
+        if (with_batch) {
+            const nerfhip_ray_batch& b = *batch_host;
+            NERFHIP_CHECK_ARG(b.c2w && b.rays && b.H > 0 && b.W > 0 && ((b.rgbs == nullptr) == (b.rgbs_all == nullptr)));
+            if (((uintptr_t)b.rays) & 15) return NERFHIP_E_ALIGN;
+            T.batch_draw = k;
+            T.batch.c2w = b.c2w; T.batch.rgbs_all = b.rgbs_all; T.batch.rays = b.rays; T.batch.rgbs = b.rgbs;
+            T.batch.H = b.H; T.batch.W = b.W; T.batch.focal = (float)b.focal; T.batch.near = b.near; T.batch.far = b.far;
+            T.batch.use_ndc = b.use_ndc; T.batch.ndc_plane = b.ndc_near_plane;
+            T.batch.sx = nerfhip_ndc_scale(b.W, b.focal); T.batch.sy = nerfhip_ndc_scale(b.H, b.focal);
+        }
+    }
+    for (int k = T.count; k <= nerfhip::kDrawMax; ++k) T.block0[k] = blocks;
+    for (int k = T.count; k < nerfhip::kDrawMax; ++k) { T.out[k] = nullptr; T.numel[k] = 0; T.rel[k] = 0; T.range[k] = 1; T.kind[k] = 0; }
+    T.total = rel;
+    if (increment_host) *increment_host = (uint64_t)rel;
+    if (T.count == 0 && !(state && rel)) return 0;
+    if (T.count == 0) {                        // only skipped draws, captured: one workgroup moves the device offset on
+        T.count = 1; T.numel[0] = 0; T.kind[0] = 0; T.block0[0] = 0;
+        for (int k = 1; k <= nerfhip::kDrawMax; ++k) T.block0[k] = 1;
+        blocks = 1;
+    }
+    hipLaunchKernelGGL(nerfhip::philox_draws_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T,
+                       (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<unsigned long long*>(state));
+    return nerfhip_launch_status();
+}

@@ -6,7 +6,7 @@
 //     g_c   = 2 (rgb_coarse - t) / n,   g_f = 2 (rgb_fine - t) / n          (d loss / d rgb, n = numel)
 // n = 3 * rays is tiny (3072 floats at 1024 rays): one 1024-thread workgroup, grid-stride loop, LDS tree
 // reduction in a fixed order (deterministic).  Latency-bound; the point is the launch count.
-#include "common.h"
+#include "loss_math.h"
 
 namespace nerfhip {
 
@@ -15,38 +15,7 @@ __global__ __launch_bounds__(1024) void mse_psnr_kernel(const float* __restrict_
                                                         float* __restrict__ out3, float* __restrict__ g_c,
                                                         float* __restrict__ g_f) {
     __shared__ float red[2][16];
-    const int tid = threadIdx.x;
-    const float scale = 2.0f / (float)n;
-    float sc = 0.f, sf = 0.f;
-    for (int64_t i = tid; i < n; i += 1024) {
-        const float t = target[i];
-        const float dc = nh_sub(rgb_c[i], t);
-        sc += nh_mul(dc, dc);
-        if (g_c) g_c[i] = nh_mul(dc, scale);
-        if (rgb_f) {
-            const float df = nh_sub(rgb_f[i], t);
-            sf += nh_mul(df, df);
-            if (g_f) g_f[i] = nh_mul(df, scale);
-        }
-    }
-    sc = wave_sum(sc);
-    sf = wave_sum(sf);
-    if ((tid & 63) == 0) {
-        red[0][tid >> 6] = sc;
-        red[1][tid >> 6] = sf;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float tc = 0.f, tf = 0.f;
-        for (int w = 0; w < 16; ++w) {
-            tc += red[0][w];
-            tf += red[1][w];
-        }
-        const float mc = tc / (float)n, mf = tf / (float)n;
-        out3[0] = rgb_f ? mc + mf : mc;                       // losses.py:10-13
-        out3[1] = -10.0f * log10f(rgb_f ? mf : mc);           // metrics.py:12-13 on the fine (else coarse) image
-        out3[2] = rgb_f ? mf : mc;
-    }
+    mse_psnr_block<1>([&](int64_t i) { return rgb_c[i]; }, [&](int64_t i) { return rgb_f[i]; }, rgb_f != nullptr, target, n, out3, g_c, g_f, red);
 }
 
 }  // namespace nerfhip

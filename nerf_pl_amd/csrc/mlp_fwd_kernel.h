@@ -19,6 +19,7 @@
 #include "common.h"
 #include "mlp_layout.h"
 #include "f8_store.h"
+#include "sampling_math.h"
 
 #ifndef NERFHIP_STORE_AUX
 #define NERFHIP_STORE_AUX 2     // cache-policy bits of the activation stores: 2 = nt (written once, read by another kernel: -7 %)
@@ -546,7 +547,7 @@ constexpr int MODE_EMBEDDED = 0, MODE_RAYS = 1;
 template <int PREC, int MODE, bool SIGMA_ONLY, int SV>
 __global__ __launch_bounds__((KCfg<PREC, (SV != 0)>::NW * 64), (KCfg<PREC, (SV != 0)>::WPS))
 void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
-                    const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save) {
+                    const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save, FwdZGen zg) {
     using Slab = typename PrecTraits<PREC>::Slab;
     constexpr bool SAVE = SV != 0, F8 = SV == 2;
     constexpr int NW = KCfg<PREC, SAVE>::NW;
@@ -580,8 +581,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     if (MODE == MODE_RAYS) {
         const int64_t S = aux;
         const int64_t ray = pc / S;
-        const float zv = in1[pc];
         const float* rp = in0 + ray * 8;
+        float zv;
+        if (zg.z_out) {      // (wave-uniform) coarse depths formed here: rendering.py:183-204
+            const float pr = zg.perturb > 0.0f ? zg.prand[pc] : 0.0f;
+            zv = coarse_z_sample(rp[6], rp[7], (int)(pc - ray * S), (int)S, zg.use_disp, zg.perturb, pr);
+            if (valid && h == 0) zg.z_out[p] = zv;
+        } else {
+            zv = in1[pc];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             dir[c] = rp[3 + c];
@@ -765,6 +773,6 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 // parallel; mlp_fwd.hip holds the C ABI and calls these launchers.
 template <int PREC, int MODE, bool SIGMA_ONLY, int SV>
 int launch_fwd_variant(const float* in0, const float* in1, int64_t n, int64_t aux, const void* packed, float* out, void* save,
-                       unsigned blocks, hipStream_t stream);
+                       unsigned blocks, hipStream_t stream, const FwdZGen& zg);
 
 }  // namespace nerfhip

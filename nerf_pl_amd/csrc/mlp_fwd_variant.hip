@@ -14,10 +14,10 @@ static_assert(KCfg<NH_PREC, kSV != 0>::NW == (NH_PREC == NERFHIP_BF16 ? 8 : 4), 
 template <>
 int launch_fwd_variant<NH_PREC, NH_MODE, NH_VARIANT == 1, kSV>(const float* in0, const float* in1, int64_t n, int64_t aux,
                                                                const void* packed, float* out, void* save, unsigned blocks,
-                                                               hipStream_t stream) {
+                                                               hipStream_t stream, const FwdZGen& zg) {
     constexpr int NW = KCfg<NH_PREC, kSV != 0>::NW;
     hipLaunchKernelGGL((mlp_fwd_kernel<NH_PREC, NH_MODE, NH_VARIANT == 1, kSV>), dim3(blocks), dim3(NW * 64), 0, stream,
-                       in0, in1, n, aux, (const uint8_t*)packed, out, (uint8_t*)save);
+                       in0, in1, n, aux, (const uint8_t*)packed, out, (uint8_t*)save, zg);
     return nerfhip_launch_status();
 }
 

@@ -24,6 +24,17 @@
 #endif
 
 namespace nerfhip {
+
+// Coarse depths formed in the prologue of the fused forward (MODE_RAYS; rendering.py:183-204): when z_out is set the kernel
+// computes z of its points itself from the ray bounds (+ the caller's jitter draw `prand` when perturb > 0), uses them and
+// writes them to z_out (B,S) for the compositing that follows — instead of reading a z tensor an earlier launch produced.
+struct FwdZGen {
+    const float* prand;
+    float* z_out;
+    int use_disp;
+    float perturb;
+};
+
 namespace mlp {
 
 constexpr int kPieceBytes = 1024;

@@ -1,0 +1,141 @@
+// Per-wave inverse-CDF sampling machinery of reference models/rendering.py:14-55, 223-229 (one ray per 64-lane wavefront, the
+// ray's cdf / bins staged in LDS), shared by the sampling kernels (sampling.hip) and the compositing kernel that appends the
+// fine-pass depth assembly to the coarse pass's quadrature (composite.hip).
+#pragma once
+#include "sampling_math.h"
+
+namespace nerfhip {
+
+// first j in [0,n] with a[j] > v   (numpy side='right')
+// first j in [0,n] with a[j] >= v  (numpy side='left')
+template <typename P>
+__device__ __forceinline__ int lower_bound(P a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <typename P>
+__device__ __forceinline__ int upper_bound(P a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- shared per-wave inverse-CDF machinery ---------------------------------------------------
+// cdf_s: M+1 floats in LDS (built here), bins_s: M+1 floats in LDS (filled by the caller).
+template <typename WLoad>
+__device__ __forceinline__ void build_cdf_wave(WLoad wload, int M, float eps, float* cdf_s, int lane) {
+    // weights + eps, total (fp64 sum of the fp32 terms, rounded once)            rendering.py:29-30
+    double part = 0.0;
+    for (int j = lane; j < M; j += 64) part += (double)nh_add(wload(j), eps);
+    const float total = (float)wave_sum(part);
+    // cdf = [0, cumsum(pdf)]                                                      :31-33
+    double carry = 0.0;
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
+        const float pdf = (j < M) ? nh_div(nh_add(wload(j), eps), total) : 0.0f;
+        const double incl = wave_incl_sum((double)pdf, lane) + carry;
+        if (j < M) cdf_s[j + 1] = (float)incl;
+        carry = __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cdf_s[0] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float invert_cdf(const float* cdf_s, const float* bins_s, int M, float u, float eps,
+                                            int* ind_out = nullptr) {
+    const int ind = upper_bound(cdf_s, M + 1, u);   // searchsorted(cdf,u,'right')   :42
+    if (ind_out) *ind_out = ind;
+    const int below = max(ind - 1, 0);              // :43
+    const int above = min(ind, M);                  // :44
+    const float cb = cdf_s[below], ca = cdf_s[above];
+    const float bb = bins_s[below], ba = bins_s[above];
+    float denom = nh_sub(ca, cb);
+    if (denom < eps) denom = 1.0f;                  // :51
+    const float t = nh_div(nh_sub(u, cb), denom);
+    return nh_add(bb, nh_mul(t, nh_sub(ba, bb)));  // :54
+}
+
+// z_fine = sort(cat(z_coarse, sample_pdf(z_mid, w[:,1:-1], N_i)))        rendering.py:223-229
+// Merge without a sort network: the coarse depths are already non-decreasing, so
+//   rank(coarse i) = i + #{new < zc_i}            = i + prefix-sum over j<=i of hist[j],  hist[ub_k]++
+//   rank(new k)    = ub_k + #{new q before k}      with ub_k = #{coarse <= zn_k} (binary search)
+// and only the new-vs-new count is quadratic (N^2/64 compares per lane, LDS reads 16 B wide, broadcast).
+__device__ __forceinline__ int fine_z_lds_floats(int S, int N) {
+    const int S4 = (S + 3) & ~3, N4 = (N + 3) & ~3;
+    return 3 * S4 + N4 + ((S + 1 + 3) & ~3) + N4;   // zc | cdf | bins | zn | hist | ub
+}
+// one ray per wave: `lds` = this wave's fine_z_lds_floats(S, N) floats; zrow = the ray's S coarse depths (global), wload(j) = its
+// coarse weight 1 + j (weights_coarse[:, 1:-1], :225: from global memory or from the LDS of the kernel that just composited them),
+// urow = its N uniforms or NULL (deterministic linspace); out = its S + N fine depths; znew / cdf_row / inds_row optional exports
+template <typename WLoad>
+__device__ __forceinline__ void fine_z_wave(float* lds, const float* __restrict__ zrow, WLoad wload, const float* __restrict__ urow,
+                                            int S, int N, float eps, float* __restrict__ out, float* __restrict__ znew,
+                                            float* __restrict__ cdf_row, int64_t* __restrict__ inds_row, int lane) {
+    const int M = S - 2;                        // number of pdf bins
+    const int S4 = (S + 3) & ~3, N4 = (N + 3) & ~3, H4 = (S + 1 + 3) & ~3;
+    float* zc_s = lds;
+    float* cdf_s = zc_s + S4;                   // M+1 = S-1
+    float* bins_s = cdf_s + S4;                 // M+1 = S-1 midpoints
+    float* zn_s = bins_s + S4;                  // N new samples, padded with +inf to a multiple of 4
+    int* hist_s = reinterpret_cast<int*>(zn_s + N4);   // S+1 counters
+    int* ub_s = hist_s + H4;                    // N upper bounds
+    for (int j = lane; j < S; j += 64) zc_s[j] = zrow[j];
+    for (int j = lane; j <= S; j += 64) hist_s[j] = 0;
+    if (lane < N4 - N) zn_s[N + lane] = __builtin_inff();
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < S - 1; j += 64) bins_s[j] = nh_mul(0.5f, nh_add(zc_s[j], zc_s[j + 1]));  // :223
+    build_cdf_wave(wload, M, eps, cdf_s, lane);
+    if (cdf_row)
+        for (int j = lane; j <= M; j += 64) cdf_row[j] = cdf_s[j];
+    for (int k = lane; k < N; k += 64) {
+        const float uk = urow ? urow[k] : linspace01(k, N);
+        int ind;
+        const float v = invert_cdf(cdf_s, bins_s, M, uk, eps, &ind);
+        if (inds_row) inds_row[k] = (int64_t)ind;
+        zn_s[k] = v;
+        if (znew) znew[k] = v;
+        const int ub = upper_bound(zc_s, S, v);  // #coarse <= v
+        ub_s[k] = ub;
+        atomicAdd(&hist_s[ub], 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // coarse elements: inclusive prefix of hist
+    int carry = 0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        int c = (i < S) ? hist_s[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(c, o, 64);
+            if (lane >= o) c += t;
+        }
+        c += carry;
+        if (i < S) out[i + c] = zc_s[i];
+        carry = __shfl(c, 63, 64);
+    }
+    // new elements: stable rank among the new ones (NaNs are not ordered)
+    const float4* zn4 = reinterpret_cast<const float4*>(zn_s);
+    for (int k = lane; k < N; k += 64) {
+        const float x = zn_s[k];
+        int rank = ub_s[k];
+#pragma unroll 4
+        for (int q4 = 0; q4 < N4 / 4; ++q4) {
+            const float4 y = zn4[q4];
+            const int q = q4 * 4;
+            rank += (y.x < x || (y.x == x && q + 0 < k)) ? 1 : 0;
+            rank += (y.y < x || (y.y == x && q + 1 < k)) ? 1 : 0;
+            rank += (y.z < x || (y.z == x && q + 2 < k)) ? 1 : 0;
+            rank += (y.w < x || (y.w == x && q + 3 < k)) ? 1 : 0;
+        }
+        out[rank] = x;
+    }
+}
+
+}  // namespace nerfhip

@@ -1,0 +1,180 @@
+"""The random draws of a training step in ONE launch, from torch's own generator stream (csrc/draws.hip).
+
+The reference draws inside `render_rays` with `torch.rand` / `torch.randn` (rendering.py:203, :152, :39, :152) and picks its batch
+through the DataLoader (train.py:89-94); on the GPU that is five ~5 us launches per step.  `draws()` produces the same tensors —
+bit for bit what those torch calls return for the generator's current (seed, offset) — from one HIP launch and advances the
+generator by what the calls would have consumed, so a run is the same run whichever path draws (`tests/test_gpu_draws.py`).
+
+hipGraph capture.  A captured launch cannot take (seed, offset) by value: every replay must walk on.  While the current stream
+is capturing, `draws()` reads them from a device-resident `GraphDrawState` that the kernel itself advances (last workgroup,
+arrival ticket); the owner of the graph (`system.GraphedTrainStep`) arms its state before the capture, captures under
+`with capturing(state)` and moves torch's generator along after every replay (`after_replay`), so eager draws made between
+replays stay on the same stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DRAW_NORMAL, DRAW_RANDINT, DRAW_UNIFORM, check, ptr, stream_ptr
+
+_KINDS = {"rand": DRAW_UNIFORM, "randn": DRAW_NORMAL, "randint": DRAW_RANDINT}
+_MAX_BLOCKS = {}
+_GRAPH_STATES = {}
+
+
+def max_blocks(device):
+    """ATen's launch cap for its distribution kernels: multiProcessorCount * (maxThreadsPerMultiProcessor / 256)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    mb = _MAX_BLOCKS.get(idx)
+    if mb is None:
+        p = torch.cuda.get_device_properties(idx)
+        mb = _MAX_BLOCKS[idx] = p.multi_processor_count * (p.max_threads_per_multi_processor // 256)
+    return mb
+
+
+def _generator(device, generator):
+    if generator is not None:
+        return generator
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch.cuda.default_generators[idx]
+
+
+class GraphDrawState:
+    """(seed, offset) of one generator in device memory, for captured launches: {seed, offset, arrival ticket, -} as 4 x int64."""
+
+    def __init__(self, device, generator=None):
+        self.device = torch.device(device)
+        self.generator = _generator(self.device, generator)
+        self.tensor = torch.zeros(4, device=self.device, dtype=torch.int64)
+        self.seed = None
+        self.expect = None         # offset the device copy holds (== the generator's, as long as nobody else drew)
+        self.increment = 0         # what ONE replay of the captured launches consumes
+
+    def arm(self):
+        """Before a capture (not during one): load the generator's current (seed, offset); forget the recorded increment."""
+        g = self.generator
+        self.seed, self.expect = int(g.initial_seed()), int(g.get_offset())
+        self.increment = 0
+        self._upload()
+
+    def _upload(self):
+        host = torch.tensor([self.seed, self.expect, 0, 0], dtype=torch.int64)
+        self.tensor.copy_(host)
+
+    def before_replay(self):
+        """The generator moved since the last replay (an eager draw, a re-seed): put the device copy back on its stream."""
+        g = self.generator
+        seed, off = int(g.initial_seed()), int(g.get_offset())
+        if seed != self.seed or off != self.expect:
+            self.seed, self.expect = seed, off
+            self._upload()
+
+    def after_replay(self):
+        """The replay advanced the device copy by `increment`: torch's generator follows (a host-side counter, no launch)."""
+        if self.increment:
+            self.expect += self.increment
+            self.generator.set_offset(self.expect)
+
+
+class capturing:
+    """`with capturing(state):` — the draw launches issued (captured) inside read their generator state from `state` and record
+    their increments there.  One state per captured graph: the graph's launches hold ITS device buffer."""
+
+    def __init__(self, state):
+        self.state = state
+
+    def __enter__(self):
+        key = self.state.device.index if self.state.device.index is not None else torch.cuda.current_device()
+        self.key, self.prev = key, _GRAPH_STATES.get(key)
+        _GRAPH_STATES[key] = self.state
+        return self.state
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            _GRAPH_STATES.pop(self.key, None)
+        else:
+            _GRAPH_STATES[self.key] = self.prev
+        return False
+
+
+def _capture_state(device):
+    return _GRAPH_STATES.get(device.index if device.index is not None else torch.cuda.current_device())
+
+
+def increment(numel, device):
+    """What one torch.rand / randn / randint call of `numel` elements advances a GPU generator's offset by."""
+    return int(_lib.load().nerfhip_torch_draw_increment(int(numel), max_blocks(device)))
+
+
+def draws(specs, device, generator=None, batch=None):
+    """specs: [("rand", shape) | ("randn", shape) | ("randint", shape, high)], at most 6, each optionally followed by False =
+    "nobody reads this draw" — returns the tensors the torch calls `torch.rand(*shape, device=device)`, ... would return IN THIS
+    ORDER for `generator` (default: the device's default generator; None for the unread ones), which is advanced exactly as by
+    those calls.  batch: an _lib.RayBatch for specs[0] (a randint over a RayStore's pixel ids): the drawn ids become rays / rgbs
+    in the same launch (rays.RayStore.sample) and are themselves not stored when specs[0] is marked unread."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.NerfHipError("nerf_pl_amd.draws runs on MI355X only (no CPU fallback); use torch.rand / randn on CPU tensors")
+    n = len(specs)
+    if not 1 <= n <= 6:
+        raise ValueError("draws: 1..6 draws per launch")
+    outs, arr = [], (_lib.Draw * n)()
+    with torch.cuda.device(device):
+        for i, sp in enumerate(specs):
+            kind = _KINDS[sp[0]]
+            shape = tuple(int(x) for x in sp[1])
+            numel = 1
+            for x in shape:
+                numel *= x
+            live = not (len(sp) > (3 if kind == DRAW_RANDINT else 2) and sp[-1] is False)
+            if kind == DRAW_RANDINT:
+                high = int(sp[2])
+                if not 1 <= high < (1 << 32):
+                    raise ValueError("draws: randint needs 1 <= high < 2^32")
+                arr[i].range = high
+            t = torch.empty(shape, device=device, dtype=torch.int64 if kind == DRAW_RANDINT else torch.float32) if live else None
+            outs.append(t)
+            arr[i].kind, arr[i].numel, arr[i].out = kind, numel, (t.data_ptr() if t is not None else None)
+        inc = ctypes.c_uint64(0)
+        bptr = ctypes.addressof(batch) if batch is not None else None
+        lib = _lib.load()
+        if torch.cuda.is_current_stream_capturing():
+            st = _capture_state(device)
+            if st is None or st.seed is None or (generator is not None and generator is not st.generator):
+                raise _lib.NerfHipError("draws() inside a hipGraph capture needs an armed GraphDrawState for its generator: capture "
+                                        "under `with draws.capturing(state)` after `state.arm()` (system.GraphedTrainStep does both)")
+            check(lib.nerfhip_torch_draws(ctypes.addressof(arr), n, bptr, 0, 0, ptr(st.tensor), max_blocks(device), ctypes.byref(inc),
+                                          stream_ptr()), "nerfhip_torch_draws")
+            st.increment += int(inc.value)
+        else:
+            g = _generator(device, generator)
+            seed, off = int(g.initial_seed()), int(g.get_offset())
+            check(lib.nerfhip_torch_draws(ctypes.addressof(arr), n, bptr, seed, off, None, max_blocks(device), ctypes.byref(inc),
+                                          stream_ptr()), "nerfhip_torch_draws")
+            g.set_offset(off + int(inc.value))
+    return outs
+
+
+def step_specs(B, S, N, perturb, noise_std):
+    """(keys, specs) of the four draws of one reference `render_rays` call in the reference's order, named as the
+    parity tests name them: perturb_rand (B,S) if perturb > 0; noise_coarse (B,S) — ALWAYS drawn by the reference (rendering.py:152),
+    read only when noise_std != 0; u (B,N) if N > 0 and perturb != 0; noise_fine (B,S+N) if N > 0, likewise."""
+    keys, specs = [], []
+    want_noise = noise_std != 0
+    if perturb > 0:
+        keys.append("perturb_rand"); specs.append(("rand", (B, S)))
+    keys.append("noise_coarse"); specs.append(("randn", (B, S), want_noise))
+    if N > 0:
+        if perturb != 0:
+            keys.append("u"); specs.append(("rand", (B, N)))
+        keys.append("noise_fine"); specs.append(("randn", (B, S + N), want_noise))
+    return keys, specs
+
+
+def step_draws(B, S, N, perturb, noise_std, device, generator=None):
+    """The draws of one `render_rays` call (step_specs) in ONE launch, as a dict; unread noise tensors are absent."""
+    keys, specs = step_specs(B, S, N, perturb, noise_std)
+    return {k: t for k, t in zip(keys, draws(specs, device, generator)) if t is not None}

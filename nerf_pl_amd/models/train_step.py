@@ -5,13 +5,18 @@ on top.  `NeRFSystem.training_step` (train.py:103-117) however always composes t
 backward -> Adam — and at ~1 ms per step the ~30 small launches and node hops of the modular form are 10-15 % of it.  This
 module runs that exact computation with the launches a fixed recipe allows:
 
-    forward   4 RNG draws (the reference's, same order: rendering.py:203, :152, :39, :152)
+    forward   1 launch   the reference's four draws (rendering.py:203, :152, :39, :152) from torch's generator stream — the
+                         values torch.rand / randn would return, the generator advanced identically   nerfhip_torch_draws
+                         (none at all when the batch brought them along: RayStore.sample(step_draws=...) draws the batch's
+                         pixels, generates its rays and makes these draws in ONE launch)
               1 launch   both models' weight images (forward + W^T)                     nerfhip_mlp_pack_weights_train_multi
-              per pass   z sampling, fused MLP forward (saving), compositing + d MSE / d rgb + compositing backward
-                                                                                          nerfhip_composite_train
-              1 launch   loss value + PSNR                                               nerfhip_mse_psnr (values only)
+              coarse     fused MLP forward (saving) that forms its own depths in the prologue     nerfhip_mlp_fwd_rays_coarse
+                         compositing + d MSE / d rgb + compositing backward + the fine pass's depths  nerfhip_composite_train_fine_z
+              fine       fused MLP forward (saving)                                      nerfhip_mlp_fwd_rays
+                         compositing + d MSE / d rgb + compositing backward + loss value and PSNR  nerfhip_composite_train_loss
     backward  per model its chain kernel, then ONE weight-gradient launch and ONE reduce launch for BOTH models
               (optionally with the Adam update applied in the reduce)                    nerfhip_mlp_bwd_multi
+ = 10 launches + Adam (round 3: 18 + Adam, round 2: ~32).
 
 Every kernel forms its values with the same expressions as the modular path, so loss, outputs and d loss / d raw are
 bit-identical to it; the parameter gradients differ only in the fp32 summation order of the split-K partials.
@@ -33,37 +38,40 @@ def fusable(models, embeddings, loss_mod):
 class _TrainRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, rays, rgbs, *params):
-        models, S, use_disp, perturb, noise_std, N, white_back, adam = cfg
+        models, S, use_disp, perturb, noise_std, N, white_back, adam, draws = cfg
         rays = rays.float().contiguous()
         rgbs = rgbs.float().contiguous()
         B = rays.shape[0]
         dev = rays.device
         dtype = models[0].mlp_dtype
-        # RNG: the reference's four draws, same order / shapes / device — issued first, consumed below
-        perturb_rand = torch.rand(B, S, device=dev) if perturb > 0 else None               # rendering.py:203
-        noise_c = torch.randn(B, S, device=dev)                                            # :152 (always drawn)
-        u = torch.rand(B, N, device=dev) if (N > 0 and perturb != 0) else None             # :39
-        noise_f = torch.randn(B, S + N, device=dev) if N > 0 else None                     # :152
+        # RNG: the reference's four draws, same order / shapes / generator stream, one launch — or the tensors the
+        # caller hands in (a batch that drew them together with its pixels; a test replaying the reference's recorded draws)
+        if draws is None:
+            from .. import draws as D
+            draws = D.step_draws(B, S, N, perturb, noise_std, dev)
+        perturb_rand = draws.get("perturb_rand") if perturb > 0 else None                  # rendering.py:203
+        noise_c, noise_f = draws.get("noise_coarse"), draws.get("noise_fine")              # :152 (read only when noise_std != 0)
+        u = draws.get("u") if (N > 0 and perturb != 0) else None                           # :39
+        if noise_std != 0 and (noise_c is None or (N > 0 and noise_f is None)):
+            raise ValueError("render_rays_train: noise_std != 0 needs the noise draws")
         packs = ops.pack_models_train(models, dtype)
         # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`
         gscale = float(np.float32(2.0) / np.float32(3 * B))
-        z = ops.sample_coarse_z(rays, S, use_disp, perturb, perturb_rand)                  # :189-204
-        acts_c = ops.alloc_acts(z.numel(), dtype, dev)
-        raw_c = ops.mlp_fwd_rays(rays, z, packs[0][0], False, dtype, save=acts_c)
-        w_c, opac_c, rgb_c, depth_c, g_raw_c = ops.composite_train(raw_c, z, rays, noise_c, noise_std, white_back, rgbs, gscale,
-                                                                   want_weights=N > 0)
-        entries = [(g_raw_c, raw_c, packs[0][1], acts_c)]
-        outs = [rgb_c, depth_c, opac_c]
-        rgb_f = None
+        acts_c = ops.alloc_acts(B * S, dtype, dev)
+        z, raw_c = ops.mlp_fwd_rays_coarse(rays, S, packs[0][0], False, dtype, use_disp, perturb, perturb_rand, save=acts_c)  # :189-207
         if N > 0:
-            zf = ops.fine_z(z, w_c, N, u=u)                                                # :223-229
+            _, opac_c, rgb_c, depth_c, g_raw_c, zf = ops.composite_train_fine_z(raw_c, z, rays, noise_c, noise_std, white_back, rgbs,
+                                                                                gscale, N, u=u)                   # :143-172, :223-229
             acts_f = ops.alloc_acts(zf.numel(), dtype, dev)
             raw_f = ops.mlp_fwd_rays(rays, zf, packs[1][0], False, dtype, save=acts_f)
-            _, opac_f, rgb_f, depth_f, g_raw_f = ops.composite_train(raw_f, zf, rays, noise_f, noise_std, white_back, rgbs, gscale,
-                                                                     want_weights=False)
-            entries.insert(0, (g_raw_f, raw_f, packs[1][1], acts_f))                      # fine model first (as autograd would)
-            outs += [rgb_f, depth_f, opac_f]
-        out3 = ops.mse_psnr_values(rgb_c, rgb_f, rgbs)                                     # losses.py:9-14, metrics.py:4-13
+            opac_f, rgb_f, depth_f, g_raw_f, out3 = ops.composite_train_loss(raw_f, zf, rays, noise_f, noise_std, white_back, rgbs,
+                                                                            gscale, rgb_coarse=rgb_c)   # + losses.py:9-14, metrics.py:4-13
+            entries = [(g_raw_f, raw_f, packs[1][1], acts_f), (g_raw_c, raw_c, packs[0][1], acts_c)]   # fine model first (as autograd would)
+            outs = [rgb_c, depth_c, opac_c, rgb_f, depth_f, opac_f]
+        else:
+            opac_c, rgb_c, depth_c, g_raw_c, out3 = ops.composite_train_loss(raw_c, z, rays, noise_c, noise_std, white_back, rgbs, gscale)
+            entries = [(g_raw_c, raw_c, packs[0][1], acts_c)]
+            outs = [rgb_c, depth_c, opac_c]
         ctx.models = [models[1], models[0]] if N > 0 else [models[0]]
         ctx.entries, ctx.dtype, ctx.adam = entries, dtype, adam
         ctx.n_params = [len(m.flat_params()) for m in models]
@@ -112,15 +120,17 @@ class _TrainRender(torch.autograd.Function):
 
 
 def render_rays_train(models, embeddings, rays, rgbs, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
-                      white_back=False, adam=None):
+                      white_back=False, adam=None, draws=None):
     """Training-mode `render_rays` + MSELoss + PSNR for one ray chunk.  Returns (results, loss, out3): `results` has the keys
     of render_rays (rendering.py:213-244; detached values: the only differentiable output is `loss`, whose backward produces
     the gradients of every parameter of `models`), out3 = [loss, psnr, mse] detached.
-    adam: an optim.FlatAdam to apply inside the backward's reduce kernel (single-GPU steps; `optimizer.step()` then skips)."""
+    adam: an optim.FlatAdam to apply inside the backward's reduce kernel (single-GPU steps; `optimizer.step()` then skips).
+    draws: {'perturb_rand', 'noise_coarse', 'u', 'noise_fine'} tensors to consume instead of drawing (draws.step_specs names the
+    shapes): what RayStore.sample(step_draws=...) put into the batch, or the reference's recorded draws in a parity test."""
     N = int(N_importance)
     use = list(models[:2]) if N > 0 else [models[0]]
     params = [p for m in use for p in m.flat_params()]
-    cfg = (use, int(N_samples), bool(use_disp), float(perturb), float(noise_std), N, bool(white_back), adam)
+    cfg = (use, int(N_samples), bool(use_disp), float(perturb), float(noise_std), N, bool(white_back), adam, draws)
     res = _TrainRender.apply(cfg, rays, rgbs, *params)
     loss, out3 = res[0], res[1]
     results = {'rgb_coarse': res[2], 'depth_coarse': res[3], 'opacity_coarse': res[4]}

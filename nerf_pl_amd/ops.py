@@ -235,6 +235,70 @@ def composite_train(raw, z, rays, noise, noise_std, white_back, target, grad_sca
     return weights, opacity, rgb, depth, g_raw
 
 
+@device_guard
+def composite_train_fine_z(raw, z, rays, noise, noise_std, white_back, target, grad_scale, n_importance, u=None, eps=1e-5,
+                           want_weights=False):
+    """The coarse pass of a training step in one launch (nerfhip_composite_train_fine_z): composite_train + fine_z on the
+    ray's weights (which stay in LDS unless want_weights).  Returns (weights | None, opacity, rgb, depth, g_raw, z_fine)."""
+    require_gpu(raw, z, rays, noise, target, u)
+    raw, z, rays, target = _c(raw), _c(z), _c(rays), _c(target)
+    B, S = z.shape
+    if raw.numel() != B * S * 4 or target.numel() != B * 3:
+        raise ValueError("composite_train_fine_z: raw must be (B,S,4) and target (B,3)")
+    noise = None if noise_std == 0 else (_c(noise) if noise is not None else None)
+    u_stride = 0
+    if u is not None:
+        u = _c(u)
+        u_stride = n_importance if u.dim() == 2 else 0
+    dev = z.device
+    weights = torch.empty(B, S, device=dev, dtype=torch.float32) if want_weights else None
+    opacity = torch.empty(B, device=dev, dtype=torch.float32)
+    rgb = torch.empty(B, 3, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, device=dev, dtype=torch.float32)
+    g_raw = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+    zf = torch.empty(B, S + n_importance, device=dev, dtype=torch.float32)
+    check(_lib.load().nerfhip_composite_train_fine_z(ptr(raw), ptr(z), ptr(rays), ptr(noise), float(noise_std), int(bool(white_back)),
+                                                     ptr(target), float(grad_scale), ptr(weights), ptr(rgb), ptr(depth), ptr(opacity),
+                                                     ptr(g_raw), B, S, ptr(u), u_stride, int(n_importance), float(eps), ptr(zf),
+                                                     stream_ptr()), "nerfhip_composite_train_fine_z")
+    return weights, opacity, rgb, depth, g_raw, zf
+
+
+_TICKETS = {}
+
+
+def _ticket(device):
+    """one zero-initialised device word per GPU for the arrival-ticket kernels (they leave it at zero)"""
+    key = device.index
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(4, device=device, dtype=torch.int32)
+    return t
+
+
+@device_guard
+def composite_train_loss(raw, z, rays, noise, noise_std, white_back, target, grad_scale, rgb_coarse=None):
+    """The last pass of a training step in one launch (nerfhip_composite_train_loss): composite_train + the values of mse_psnr
+    over (rgb_coarse, this pass's rgb).  Returns (opacity, rgb, depth, g_raw, out3 = [loss, psnr, mse])."""
+    require_gpu(raw, z, rays, noise, target, rgb_coarse)
+    raw, z, rays, target = _c(raw), _c(z), _c(rays), _c(target)
+    B, S = z.shape
+    if raw.numel() != B * S * 4 or target.numel() != B * 3 or (rgb_coarse is not None and rgb_coarse.numel() != B * 3):
+        raise ValueError("composite_train_loss: raw must be (B,S,4), target and rgb_coarse (B,3)")
+    noise = None if noise_std == 0 else (_c(noise) if noise is not None else None)
+    dev = z.device
+    opacity = torch.empty(B, device=dev, dtype=torch.float32)
+    rgb = torch.empty(B, 3, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, device=dev, dtype=torch.float32)
+    g_raw = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+    out3 = torch.empty(3, device=dev, dtype=torch.float32)
+    check(_lib.load().nerfhip_composite_train_loss(ptr(raw), ptr(z), ptr(rays), ptr(noise), float(noise_std), int(bool(white_back)),
+                                                   ptr(target), float(grad_scale), None, ptr(rgb), ptr(depth), ptr(opacity), ptr(g_raw),
+                                                   B, S, ptr(_c(rgb_coarse)) if rgb_coarse is not None else None, ptr(out3),
+                                                   ptr(_ticket(dev)), stream_ptr()), "nerfhip_composite_train_loss")
+    return opacity, rgb, depth, g_raw, out3
+
+
 # ------------------------------------------------------------------------------- loss + PSNR (N2)
 class _MsePsnr(torch.autograd.Function):
     @staticmethod
@@ -410,6 +474,25 @@ def mlp_fwd_rays(rays, z, packed, sigma_only, dtype, save=None):
     check(_lib.load().nerfhip_mlp_fwd_rays(ptr(rays), ptr(z), B, S, ptr(packed), ptr(out), int(bool(sigma_only)),
                                            mlp_dtype_code(dtype), ptr(save), stream_ptr()), "nerfhip_mlp_fwd_rays")
     return out
+
+
+@device_guard
+def mlp_fwd_rays_coarse(rays, n_samples, packed, sigma_only, dtype, use_disp=False, perturb=0.0, perturb_rand=None, save=None):
+    """The coarse pass's sample_coarse_z + mlp_fwd_rays in one launch (nerfhip_mlp_fwd_rays_coarse): the depths are formed in the
+    MLP kernel's prologue.  Returns (z (B,S), out)."""
+    require_gpu(rays, perturb_rand)
+    rays = _c(rays)
+    B, S = rays.shape[0], int(n_samples)
+    if perturb > 0:
+        if perturb_rand is None:
+            raise ValueError("perturb>0 needs perturb_rand")
+        perturb_rand = _c(perturb_rand)
+    z = torch.empty(B, S, device=rays.device, dtype=torch.float32)
+    out = torch.empty((B, S) if sigma_only else (B, S, 4), device=rays.device, dtype=torch.float32)
+    check(_lib.load().nerfhip_mlp_fwd_rays_coarse(ptr(rays), ptr(perturb_rand if perturb > 0 else None), ptr(z), B, S,
+                                                  int(bool(use_disp)), float(perturb), ptr(packed), ptr(out), int(bool(sigma_only)),
+                                                  mlp_dtype_code(dtype), ptr(save), stream_ptr()), "nerfhip_mlp_fwd_rays_coarse")
+    return z, out
 
 
 # ------------------------------------------------------------------------------- MLP backward (K2b)

@@ -31,21 +31,28 @@ def render_sharded(render_fn, rays, keys=("rgb_fine", "depth_fine", "opacity_fin
     local = render_fn(rays[lo:hi])
     if world == 1:
         return {k: local[k] for k in keys if k in local}
-    out = {}
+    # ONE collective per image: the requested keys travel as the columns of one (maxlen, C) buffer (rgb 3 + depth 1 + opacity 1
+    # = 5 floats per ray; at 8 ranks the 0.96 MB gather is latency-bound, so the count of collectives is what matters)
+    have = [k for k in keys if k in local]
+    if not have:
+        return {}
+    cols = [int(torch.Size(local[k].shape[1:]).numel()) for k in have]          # (rows, ...) -> columns per row (1 for a vector)
     maxlen = shard_bounds(n, 0, world)[1]
-    for k in keys:
-        if k not in local:
-            continue
-        v = local[k]
-        pad = torch.zeros((maxlen,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        pad[: v.shape[0]] = v
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad, group=group)
-        parts = []
-        for r in range(world):
-            a, b = shard_bounds(n, r, world)
-            parts.append(bufs[r][: b - a])
-        out[k] = torch.cat(parts, 0)
+    v0 = local[have[0]]
+    pack = torch.zeros(maxlen, sum(cols), dtype=v0.dtype, device=v0.device)
+    c = 0
+    for k, w in zip(have, cols):
+        pack[: hi - lo, c:c + w] = local[k].reshape(hi - lo, w)
+        c += w
+    gathered = torch.empty(world * maxlen, sum(cols), dtype=v0.dtype, device=v0.device)
+    dist.all_gather_into_tensor(gathered, pack, group=group)
+    rows = torch.cat([gathered[r * maxlen: r * maxlen + (shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0])]
+                      for r in range(world)], 0)
+    out, c = {}, 0
+    for k, w in zip(have, cols):
+        col = rows[:, c:c + w]
+        out[k] = col.reshape((n,) + tuple(local[k].shape[1:])) if local[k].dim() > 1 else col.reshape(n)
+        c += w
     return out
 
 
@@ -84,6 +91,16 @@ class GradSync:
         for m in self.models:
             if getattr(m, "_grad_ready_hook", None) == self._on_grad_ready:
                 m._grad_ready_hook = None
+
+    def agree_any(self, flag):
+        """True on every rank if `flag` is true on any (one small eager MAX all-reduce): ranks that must take the same branch —
+        e.g. GraphedTrainStep falling back to two graphs when the one-graph capture failed somewhere — decide it here."""
+        if not self.active():
+            return bool(flag)
+        dev = next(self.models[0].parameters()).device
+        t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
 
     def _avg_op(self):
         """(reduce op, needs_division): RCCL averages in the collective itself; gloo (CPU tests) has no AVG."""

@@ -88,18 +88,36 @@ class RayStore:
     def __len__(self):
         return self.n_pixels
 
-    def sample(self, batch_size, generator=None):
-        """One training batch: pixel ids drawn on the GPU, their rays generated and their colours gathered in ONE launch
-        (nerfhip_sample_batch)."""
+    def sample(self, batch_size, generator=None, step_draws=None, return_ids=False):
+        """One training batch in ONE launch (nerfhip_torch_draws with a ray batch): the pixel ids torch.randint(0, n_pixels,
+        (batch_size,)) would draw from `generator` (default: the device's default generator, advanced identically), their rays
+        and their colours.
+        step_draws = (N_samples, N_importance, perturb, noise_std): the same launch also makes the draws the training step's
+        render_rays will need (draws.step_specs: the reference's rand / randn calls, in its order, right after the batch's
+        randint on the generator's stream) and returns them under batch['draws'] for NeRFSystem.training_step."""
+        from . import draws as D
         dev = self.poses.device
-        ids = torch.randint(0, self.n_pixels, (batch_size,), device=dev, generator=generator)
-        rays = torch.empty(batch_size, 8, device=dev, dtype=torch.float32)
-        rgbs = torch.empty(batch_size, 3, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
-            check(_lib.load().nerfhip_sample_batch(ptr(self.poses), ptr(ids), ptr(self.rgbs), int(batch_size), self.H, self.W,
-                                                   self.focal, self.near, self.far, int(self.use_ndc), self.ndc_near_plane, ptr(rays),
-                                                   ptr(rgbs), stream_ptr()), "nerfhip_sample_batch")
-        return {"rays": rays, "rgbs": rgbs}
+        B = int(batch_size)
+        if self.n_pixels >= (1 << 32):
+            raise _lib.NerfHipError("RayStore.sample: more than 2^32 pixels")
+        rays = torch.empty(B, 8, device=dev, dtype=torch.float32)
+        rgbs = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        rb = _lib.RayBatch()
+        rb.c2w, rb.rgbs_all, rb.rays, rb.rgbs = self.poses.data_ptr(), self.rgbs.data_ptr(), rays.data_ptr(), rgbs.data_ptr()
+        rb.H, rb.W, rb.focal, rb.near, rb.far = self.H, self.W, self.focal, self.near, self.far
+        rb.use_ndc, rb.ndc_near_plane = int(self.use_ndc), self.ndc_near_plane
+        specs, keys = [("randint", (B,), self.n_pixels, bool(return_ids))], []
+        if step_draws is not None:
+            S, N, perturb, noise_std = step_draws
+            keys, more = D.step_specs(B, int(S), int(N), float(perturb), float(noise_std))
+            specs += more
+        outs = D.draws(specs, dev, generator, batch=rb)
+        batch = {"rays": rays, "rgbs": rgbs}
+        if return_ids:
+            batch["ids"] = outs[0]
+        if step_draws is not None:
+            batch["draws"] = {k: t for k, t in zip(keys, outs[1:]) if t is not None}
+        return batch
 
     def image_rays(self, i):
         hw = self.H * self.W

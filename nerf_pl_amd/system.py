@@ -120,9 +120,13 @@ class NeRFSystem(_Base):
         if self._fused_step_ok(rays):
             from .models.train_step import render_rays_train
             hp = self.hp
-            adam = self.optimizer if (self.fuse_adam and type(self.optimizer).__name__ == 'FlatAdam') else None
+            adam = self.optimizer if (self.fuse_adam and type(self.optimizer).__name__ == 'FlatAdam'
+                                      and self._fused_adam_ok()) else None
+            # a batch from RayStore.sample(step_draws=...) brings the step's random draws along (made in the launch that drew its
+            # pixels); otherwise the fused node makes them itself — either way from torch's generator stream
+            draws = batch.get('draws') if isinstance(batch, dict) else None
             results, loss, out3 = render_rays_train(self.models, self.embeddings, rays, rgbs, hp.N_samples, hp.use_disp, hp.perturb,
-                                                    hp.noise_std, hp.N_importance, self.white_back, adam=adam)
+                                                    hp.noise_std, hp.N_importance, self.white_back, adam=adam, draws=draws)
             self.loss.last = out3
             log['train/loss'] = loss
             psnr_ = out3[1]
@@ -137,6 +141,15 @@ class NeRFSystem(_Base):
                     psnr_ = psnr(results[f'rgb_{typ}'], rgbs)
         log['train/psnr'] = psnr_
         return {'loss': loss, 'progress_bar': {'train_psnr': psnr_}, 'log': log}
+
+    def _fused_adam_ok(self):
+        """Adam inside the backward's reduce kernel is only the reference's step when nothing sits between the gradients and the
+        update: one rank (no all-reduce: with several ranks the update would use LOCAL gradients and the replicas diverge) and
+        no accumulated gradients (the update would be applied once per backward)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        return all(p.grad is None for m in self.models for p in m.parameters())
 
     def _fused_step_ok(self, rays):
         if not (self.fused_train_step and torch.is_grad_enabled() and rays.is_cuda and rays.dim() == 2
@@ -213,6 +226,7 @@ class GraphedTrainStep:
         self.static_out = None
         self.captured_lr = None
         self.capture_fallback = None      # repr of the exception that made the one-graph capture fall back to two graphs
+        self._draw_state = None           # draws.GraphDrawState: the generator stream of the captured draw launches
         # `backend` abstracts the three device facilities the stepper needs (side stream, graph capture, replay) so the
         # host logic — warm-up, capture, two-graph step with the eager collective in between, re-capture on lr change —
         # can be exercised by the world-2 gloo CPU test with a recording stand-in (tests/test_distributed_cpu.py).
@@ -251,34 +265,62 @@ class GraphedTrainStep:
         if self.grad_sync is not None and hasattr(self.grad_sync, "hooks_enabled"):
             self.grad_sync.hooks_enabled = on
 
+    def _arm_draws(self):
+        """The captured step's draw launches (draws.py) read their (seed, offset) from device memory: load it from torch's
+        generator before the capture."""
+        p = next(iter(self.system.parameters()), None)
+        if p is None or not p.is_cuda:
+            return
+        from .draws import GraphDrawState
+        if self._draw_state is None:
+            self._draw_state = GraphDrawState(p.device)       # one per stepper: its graphs' launches hold this device buffer
+        self._draw_state.arm()
+
+    def _capture_with_draws(self, fn, **kw):
+        if self._draw_state is None:
+            return self.backend.capture(fn, **kw)
+        from .draws import capturing
+        with capturing(self._draw_state):
+            return self.backend.capture(fn, **kw)
+
     def _capture(self, batch):
-        self.static_batch = {k: v.clone() for k, v in batch.items()} if batch is not None else None
+        self.static_batch = {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()})
+                             for k, v in batch.items()} if batch is not None else None
         self.captured_lr = get_learning_rate(self.opt)
+        self._arm_draws()
         self.static_out = None
         self.graph_opt = None
         if not self._two_graphs():
             # one graph: forward, backward, [all-reduces issued from the grad-ready hooks, i.e. overlapping the rest of
             # the backward also on replay], optimizer
+            err = None
             try:
-                self.graph, self.static_out = self.backend.capture(lambda: self._eager(self.static_batch))
-            except Exception as e:      # noqa: BLE001
+                self.graph, self.static_out = self._capture_with_draws(lambda: self._eager(self.static_batch))
+            except RuntimeError as e:       # what a failed stream capture / a collective that cannot be captured raises
                 if self.grad_sync is None:
                     raise
-                # a communicator whose collectives cannot be captured on this stack (every rank runs the same software, so
-                # every rank lands here together): keep the collectives outside the graphs instead
+                err = e
+            # A communicator whose collectives cannot be captured on this stack: keep the collectives outside the graphs
+            # instead.  EVERY rank must take the same branch (one rank replaying a captured all-reduce while another issues an
+            # eager one deadlocks), so the ranks agree on it with a collective of its own, outside any capture.
+            failed = err is not None
+            if self.grad_sync is not None and hasattr(self.grad_sync, "agree_any"):
+                failed = self.grad_sync.agree_any(failed)
+            if failed:
                 import warnings
                 warnings.warn("GraphedTrainStep: capturing the step with its all-reduces inside failed (%r); falling back to two "
-                              "graphs with the collectives issued eagerly in between" % (e,))
-                self.capture_fallback = repr(e)
+                              "graphs with the collectives issued eagerly in between" % (err,))
+                self.capture_fallback = repr(err) if err is not None else "another rank's capture failed"
                 self.sync_in_graph = False
                 self.graph = None
                 getattr(self.grad_sync, "_inflight", {}).clear()
+                self._arm_draws()           # the aborted capture recorded draw increments that will not be replayed
         if self._two_graphs():
             # two graphs with the collectives issued eagerly in between: the hooks must stay silent, or the fine
             # model's all-reduce would be captured into the first graph
             self._set_hooks(False)
             try:
-                self.graph, self.static_out = self.backend.capture(lambda: self._fwd_bwd(self.static_batch))
+                self.graph, self.static_out = self._capture_with_draws(lambda: self._fwd_bwd(self.static_batch))
                 self.graph_opt, _ = self.backend.capture(self.opt.step, share_pool_with=self.graph)
             finally:
                 self._set_hooks(True)
@@ -290,12 +332,21 @@ class GraphedTrainStep:
         if self.calls <= self.warmup:
             return self.backend.on_side_stream(self._eager, batch)
         if (self.graph is None or get_learning_rate(self.opt) != self.captured_lr
-                or (batch is not None and any(batch[k].shape != self.static_batch[k].shape for k in batch))):
+                or (batch is not None and any(torch.is_tensor(batch[k]) and batch[k].shape != self.static_batch[k].shape for k in batch))):
             self._capture(batch)
         elif batch is not None:
             for k, v in batch.items():
-                self.static_batch[k].copy_(v, non_blocking=True)
+                if torch.is_tensor(v):
+                    self.static_batch[k].copy_(v, non_blocking=True)
+                else:
+                    for kk, vv in v.items():
+                        self.static_batch[k][kk].copy_(vv, non_blocking=True)
+        ds = self._draw_state
+        if ds is not None and ds.increment:
+            ds.before_replay()
         self.graph.replay()
+        if ds is not None:
+            ds.after_replay()
         if self.graph_opt is not None:
             self.grad_sync.sync()
             self.graph_opt.replay()
@@ -309,8 +360,9 @@ class _HipGraphBackend:
     were created on, and a node created on the default stream while a later backward is being captured on another
     stream is undefined behaviour (observed: silently missing parameter updates, or a segfault)."""
 
-    def __init__(self):
+    def __init__(self, keep_graph=False):
         self.stream = torch.cuda.Stream()
+        self.keep_graph = keep_graph         # keep the captured hipGraph_t next to its executable (node_count)
 
     def on_side_stream(self, fn, *args):
         self.stream.wait_stream(torch.cuda.current_stream())
@@ -320,7 +372,7 @@ class _HipGraphBackend:
         return out
 
     def capture(self, fn, share_pool_with=None):
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         kw = {"pool": share_pool_with.pool()} if share_pool_with is not None else {}
         # thread_local: with a process group alive, RCCL's watchdog THREAD polls the events of earlier eager collectives; under
@@ -329,3 +381,18 @@ class _HipGraphBackend:
         with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local", **kw):
             out = fn()
         return graph, out
+
+
+def graph_node_count(graph):
+    """Number of nodes (kernel launches, copies, ...) of a captured `torch.cuda.CUDAGraph(keep_graph=True)`: hipGraphGetNodes on
+    its raw hipGraph_t.  None when the handle is not available."""
+    import ctypes
+    try:
+        raw = graph.raw_cuda_graph()
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        return int(n.value)
+    except Exception:  # noqa: BLE001 - a diagnostic, never fatal
+        return None
