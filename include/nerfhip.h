@@ -315,7 +315,7 @@ int nerfhip_sample_batch(const float* c2w, const int64_t* pixel_ids, const float
  * offset + increment: same seed => same training run, whichever path draws).  max_blocks = multiProcessorCount *
  * (maxThreadsPerMultiProcessor / 256) of the device (ATen's launch cap; 2048 on MI355X).
  *   kind UNIFORM: out = numel floats of torch.rand; NORMAL: torch.randn; RANDINT: numel int64 of torch.randint(0, range)
- *   (range < 2^32).  A draw with out == NULL (and no batch) is one nobody reads — the reference always draws its noise tensors,
+ *   (range <= 2^62).  A draw with out == NULL (and no batch) is one nobody reads — the reference always draws its noise tensors,
  *   also when noise_std == 0 (rendering.py:152): the stream moves past it exactly as the torch call would, nothing is computed.
  * batch_host (NULL ok): draws_host[0] must then be RANDINT over the store's pixel ids; the drawn ids are turned into the
  * training batch in the same launch — rays (numel,8) and rgbs (numel,3) exactly as nerfhip_sample_batch — and draws_host[0].out

@@ -318,6 +318,34 @@ __global__ __launch_bounds__(256) void composite_train_kernel(const float* __res
                          lds + (size_t)wave * S, nullptr, lane);
 }
 
+// the weights of one ray (the forward sweep above without the colours) into LDS: w_s[i] = alpha_i T_i, same expressions, same bits
+__device__ __forceinline__ void composite_weights_wave(const float* __restrict__ raw, const float* __restrict__ z,
+                                                       const float* __restrict__ rays, const float* __restrict__ noise,
+                                                       float noise_std, int64_t r, int S, float* w_s, int lane) {
+    const float dnorm = ray_dnorm(rays, r);
+    const float* zr = z + r * S;
+    double carry = 1.0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < S;
+        float sigma = 0.f, zi = 0.f, zn = 0.f, nz = 0.f;
+        if (valid) {
+            zi = zr[i];
+            zn = (i + 1 < S) ? zr[i + 1] : zi;
+            sigma = raw[(r * S + i) * 4 + 3];
+            if (noise) nz = nh_mul(noise[r * S + i], noise_std);
+        }
+        const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);
+        const double f = valid ? (double)t.sh : 1.0;
+        const double incl = wave_incl_prod(f, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(excl * carry);
+        carry = carry * __shfl(incl, 63, 64);
+        if (valid) w_s[i] = nh_mul(t.alpha, T);
+    }
+}
+
 // The coarse pass of a training step: composite_train_kernel + the fine-pass depth assembly of rendering.py:223-229
 // (fine_z_kernel of sampling.hip: z_mid, sample_pdf on weights[:, 1:-1], sort(cat)) for the same ray in the same wave — the
 // weights go from the quadrature to the inverse-CDF sampling through LDS and need not exist in HBM at all (`weights` NULL).
@@ -330,18 +358,25 @@ __global__ __launch_bounds__(256) void composite_train_fine_z_kernel(const float
                                                                      float* __restrict__ g_raw, int64_t B, int S,
                                                                      const float* __restrict__ u, int64_t u_stride, int N, float eps,
                                                                      float* __restrict__ z_fine) {
+    // Two rays per workgroup, two waves per ray — both chains are latency-bound and independent once the weights exist, so they
+    // run side by side: waves 0-1 composite (quadrature, loss gradient, backward sweep), waves 2-3 form the same rays' weights
+    // again (forward sweep only, raw is in L2) and assemble the fine depths from them.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t r = (int64_t)blockIdx.x * 2 + (wave & 1);
     if (r >= B) return;
     const int S4 = (S + 3) & ~3;
-    float* T_s = lds + (size_t)wave * (2 * S4 + fine_z_lds_floats(S, N));
-    float* w_s = T_s + S4;
-    composite_train_wave(raw, z, rays, noise, noise_std, white_back, target, gscale, weights, rgb, depth, opacity, g_raw, r, S, T_s,
-                         w_s, lane);
-    __builtin_amdgcn_wave_barrier();
-    fine_z_wave(w_s + S4, z + r * S, [&](int j) { return w_s[1 + j]; }, u ? u + r * u_stride : nullptr, S, N, eps,
-                z_fine + r * (S + N), nullptr, nullptr, nullptr, lane);
+    float* base = lds + (size_t)(wave & 1) * (2 * S4 + fine_z_lds_floats(S, N));
+    if (wave < 2) {
+        composite_train_wave(raw, z, rays, noise, noise_std, white_back, target, gscale, weights, rgb, depth, opacity, g_raw, r, S,
+                             base, nullptr, lane);
+    } else {
+        float* w_s = base + S4;
+        composite_weights_wave(raw, z, rays, noise, noise_std, r, S, w_s, lane);
+        __builtin_amdgcn_wave_barrier();
+        fine_z_wave(w_s + S4, z + r * S, [&](int j) { return w_s[1 + j]; }, u ? u + r * u_stride : nullptr, S, N, eps,
+                    z_fine + r * (S + N), nullptr, nullptr, nullptr, lane);
+    }
 }
 
 // The fine (last) pass of a training step: composite_train_kernel + the step's loss values (mse_psnr_kernel of loss.hip without
@@ -447,12 +482,12 @@ extern "C" int nerfhip_composite_train_fine_z(const float* raw, const float* z, 
     NERFHIP_CHECK_ARG(B >= 0 && S >= 3 && S <= 2048 && N_i >= 1);
     const int S4 = (S + 3) & ~3, N4 = (N_i + 3) & ~3;
     const size_t per_wave = (size_t)(2 * S4 + 3 * S4 + N4 + ((S + 1 + 3) & ~3) + N4) * sizeof(float);
-    NERFHIP_CHECK_ARG(4 * per_wave <= 65536);
+    NERFHIP_CHECK_ARG(2 * per_wave <= 65536);
     if (B == 0) return 0;
     NERFHIP_CHECK_ARG(raw && z && rays && target && rgb && depth && opacity && g_raw && z_fine);
     if ((((uintptr_t)raw) | ((uintptr_t)g_raw)) & 15) return NERFHIP_E_ALIGN;
     if (noise_std == 0.0f) noise = nullptr;
-    hipLaunchKernelGGL(nerfhip::composite_train_fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 4 * per_wave,
+    hipLaunchKernelGGL(nerfhip::composite_train_fine_z_kernel, dim3((unsigned)((B + 1) / 2)), dim3(256), 2 * per_wave,
                        (hipStream_t)stream, raw, z, rays, noise, noise_std, white_back, target, grad_scale, weights, rgb, depth,
                        opacity, g_raw, B, S, u, u_stride, N_i, eps, z_fine);
     return nerfhip_launch_status();

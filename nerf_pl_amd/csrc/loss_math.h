@@ -17,13 +17,41 @@ __device__ __forceinline__ void mse_psnr_block(LoadC load_c, LoadF load_f, bool 
                                                const float* __restrict__ target, int64_t n, float* __restrict__ out3,
                                                float* __restrict__ g_c, float* __restrict__ g_f, float (*red)[16]) {
     constexpr int NT = 1024 / Q;
+    constexpr int J = 4;              // elements per stand-in thread fetched up front (n <= 4096 floats: 1365 rays, the training batch)
     const int tid = threadIdx.x;
     const float scale = 2.0f / (float)n;
+    // every load of the first J rounds is issued before the first addition: the loads of one thread are independent, the
+    // additions are not (a 256-thread tail would otherwise pay Q * n / 1024 dependent memory round trips)
+    float tv[Q][J], cv[Q][J], fv[Q][J];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int64_t i = tid + NT * q + 1024 * j;
+            const bool ok = i < n;
+            tv[q][j] = ok ? target[i] : 0.0f;
+            cv[q][j] = ok ? load_c(i) : 0.0f;
+            fv[q][j] = (ok && have_f) ? load_f(i) : 0.0f;
+        }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int v = tid + NT * q;
         float sc = 0.f, sf = 0.f;
-        for (int64_t i = v; i < n; i += 1024) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int64_t i = v + 1024 * j;
+            if (i < n) {
+                const float dc = nh_sub(cv[q][j], tv[q][j]);
+                sc += nh_mul(dc, dc);
+                if (g_c) g_c[i] = nh_mul(dc, scale);
+                if (have_f) {
+                    const float df = nh_sub(fv[q][j], tv[q][j]);
+                    sf += nh_mul(df, df);
+                    if (g_f) g_f[i] = nh_mul(df, scale);
+                }
+            }
+        }
+        for (int64_t i = v + 1024 * J; i < n; i += 1024) {
             const float t = target[i];
             const float dc = nh_sub(load_c(i), t);
             sc += nh_mul(dc, dc);

@@ -38,6 +38,7 @@ def max_blocks(device):
 def _generator(device, generator):
     if generator is not None:
         return generator
+    torch.cuda.init()                      # (the tuple of default generators is empty until the runtime is initialised)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     return torch.cuda.default_generators[idx]
 
@@ -132,8 +133,8 @@ def draws(specs, device, generator=None, batch=None):
             live = not (len(sp) > (3 if kind == DRAW_RANDINT else 2) and sp[-1] is False)
             if kind == DRAW_RANDINT:
                 high = int(sp[2])
-                if not 1 <= high < (1 << 32):
-                    raise ValueError("draws: randint needs 1 <= high < 2^32")
+                if not 1 <= high <= (1 << 62):
+                    raise ValueError("draws: randint needs 1 <= high <= 2^62")
                 arr[i].range = high
             t = torch.empty(shape, device=device, dtype=torch.int64 if kind == DRAW_RANDINT else torch.float32) if live else None
             outs.append(t)

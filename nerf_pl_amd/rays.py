@@ -98,8 +98,6 @@ class RayStore:
         from . import draws as D
         dev = self.poses.device
         B = int(batch_size)
-        if self.n_pixels >= (1 << 32):
-            raise _lib.NerfHipError("RayStore.sample: more than 2^32 pixels")
         rays = torch.empty(B, 8, device=dev, dtype=torch.float32)
         rgbs = torch.empty(B, 3, device=dev, dtype=torch.float32)
         rb = _lib.RayBatch()

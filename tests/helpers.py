@@ -1,7 +1,7 @@
 import torch  # noqa: F401
 
 from oracle import nerf_oracle as O
-from oracle.replay import ReplayRNG, hip_render  # noqa: F401  (checker plumbing lives under oracle/, not in the test tree)
+from oracle.replay import ReplayRNG, fused_draws, hip_render  # noqa: F401  (checker plumbing lives under oracle/, not in the test tree)
 from oracle.scenes import analytic_field, analytic_scene, brick_field, brick_scene  # noqa: F401
 
 

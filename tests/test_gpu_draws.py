@@ -36,7 +36,8 @@ def test_rand_randn_equal_torch(dev, shape):
         assert torch.equal(got, want), (kind, shape, (got != want).sum().item(), (got - want).abs().max().item())
 
 
-@pytest.mark.parametrize("n,high", [(1024, 20 * 200 * 200), (4096, 7), (100000, 2 ** 31 + 11), (1, 1)])
+@pytest.mark.parametrize("n,high", [(1024, 20 * 200 * 200), (4096, 7), (100000, 2 ** 31 + 11), (1, 1), (5000, 2 ** 28 - 1), (5000, 2 ** 28),
+                                    (700000, 2 ** 40 + 3)])
 def test_randint_equals_torch(dev, n, high):
     from nerf_pl_amd import draws as D
     torch.manual_seed(99)

@@ -111,13 +111,13 @@ def test_sample_pdf_vs_reference_golden(golden, dev):
         out = sample_pdf(bins, w, n, det=True).cpu()
         close = (out - golden[f"sp_det{n}"]).abs() <= 2e-6
         report.append(("det%d" % n, 1.0 - close.float().mean().item()))
-        assert close.float().mean().item() > 0.99            # measured 0.3-0.5 % (knife edges of the +-2 ulp row total)
+        assert close.float().mean().item() > 0.992           # measured 0.3-0.5 % misses (knife edges of the +-2 ulp row total)
         assert bool(O.matches_some_total_rounding(out, cb, cw, n).all())
     ur = golden["sp_rand_u"]
     out = ops.sample_pdf_u(bins, w, 128, u=ur.to(dev)).cpu()
     close = (out - golden["sp_rand128"]).abs() <= 2e-6
     report.append(("rand128", 1.0 - close.float().mean().item()))
-    assert close.float().mean().item() > 0.99
+    assert close.float().mean().item() > 0.992
     assert bool(O.matches_some_total_rounding(out, cb, cw, 128, u=ur).all())
     print("sample_pdf: fraction of samples differing from the reference-minted vectors by > 2e-6:",
           ", ".join("%s %.4f" % r for r in report))
@@ -190,7 +190,7 @@ def test_fine_z_vs_oracle(dev):
         zf = torch.sort(torch.cat([z, zn], -1), -1)[0]
         got_f, got_n = ops.fine_z(z.to(dev), w.to(dev), N, u=None if u is None else u.to(dev), return_new=True)
         got_n, got_f = got_n.cpu(), got_f.cpu()
-        assert ((got_n - zn).abs() <= 2e-6).float().mean().item() > 0.97
+        assert ((got_n - zn).abs() <= 2e-6).float().mean().item() > 0.985        # measured 0.3-0.5 % misses
         assert bool(O.matches_some_total_rounding(got_n, mid, w[:, 1:-1], N, u=u).all())
         assert bool((got_f[:, 1:] >= got_f[:, :-1]).all())
         # exactly a permutation of cat(z, z_new) as produced on the device

@@ -95,8 +95,30 @@ def test_training_grads_fp32_vs_reference_golden(golden, dev, prefix):
     tgt = golden[f"{prefix}_target"].to(dev)
     loss = torch.nn.functional.mse_loss(res["rgb_coarse"], tgt) + torch.nn.functional.mse_loss(res["rgb_fine"], tgt)
     loss.backward()
+    _check_against_reference_gradients(golden, prefix, ms, loss, res["rgb_fine"])
+
+
+@pytest.mark.parametrize("prefix", ["gr", "gr3", "gr4"])
+def test_fused_training_node_fp32_vs_reference_golden(golden, dev, prefix):
+    """The node bench.py TIMES — models/train_step.render_rays_train: one autograd node, the fused launches of round 4 (coarse
+    depths in the MLP prologue, compositing + loss gradient + compositing backward + fine depths / loss per pass, one dW and one
+    reduce launch for both models) — pinned DIRECTLY to the reference-minted gradients of the same three cases, on the draws the
+    reference consumed when they were minted (round 3 reached the goldens only through the modular graph)."""
+    from helpers import fused_draws
+    from nerf_pl_amd.models.train_step import render_rays_train
+    params, rays, kw, rng = case_from_golden(golden, None, prefix=prefix)
+    ms, emb = build_models(params, dev, "fp32")
+    tgt = golden[f"{prefix}_target"].to(dev)
+    res, loss, out3 = render_rays_train(ms, emb, rays.to(dev), tgt, kw["N_samples"], kw["use_disp"], kw["perturb"], kw["noise_std"],
+                                        kw["N_importance"], kw["white_back"], draws=fused_draws(rng, kw, dev))
+    loss.backward()
+    assert out3[0].item() == loss.item()
+    _check_against_reference_gradients(golden, prefix, ms, loss, res["rgb_fine"])
+
+
+def _check_against_reference_gradients(golden, prefix, ms, loss, rgb_fine):
     assert abs(loss.item() - golden[f"{prefix}_loss"].item()) <= 1e-4 * abs(golden[f"{prefix}_loss"].item())
-    assert torch.allclose(res["rgb_fine"].detach().cpu(), golden[f"{prefix}_rgb_fine"], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(rgb_fine.detach().cpu(), golden[f"{prefix}_rgb_fine"], rtol=1e-4, atol=1e-4)
     for tag, m in (("c", ms[0]), ("f", ms[1])):
         for n, prm in m.named_parameters():
             dig = O.grad_digest(prm.grad.cpu())

@@ -48,6 +48,22 @@ def main():
           "sample_coarse_z %.2f us" % graph_time(lambda: ops.sample_coarse_z(rays, S, False, 1.0, pr)),
           "composite_train(192) %.2f us" % graph_time(lambda: ops.composite_train(raw, zf, rays, noise, 1.0, True, tgt, 1e-3, want_weights=False)),
           flush=True)
+    # round 4: the fused launches next to what they replace
+    from nerf_pl_amd import draws as D
+    from nerf_pl_amd.rays import RayStore
+    raw_c = torch.randn(B, S, 4, device=dev)
+    rgb_c = torch.rand(B, 3, device=dev)
+    st = RayStore(torch.eye(3, 4).repeat(20, 1, 1).to(dev), torch.rand(20 * 200 * 200, 3, device=dev), 200, 200, 300.0, 2.0, 6.0)
+    ds = D.GraphDrawState(dev)
+    ds.arm()
+    with D.capturing(ds):
+        print("composite_train(64) %.2f us" % graph_time(lambda: ops.composite_train(raw_c, z, rays, None, 0.0, True, tgt, 1e-3, want_weights=True)),
+              "composite_train_fine_z(64,128) %.2f us" % graph_time(lambda: ops.composite_train_fine_z(raw_c, z, rays, None, 0.0, True, tgt, 1e-3, N, u=u)),
+              "composite_train_loss(192) %.2f us" % graph_time(lambda: ops.composite_train_loss(raw, zf, rays, None, 0.0, True, tgt, 1e-3, rgb_coarse=rgb_c)),
+              "mse_psnr %.2f us" % graph_time(lambda: ops.mse_psnr_values(rgb_c, rgb_c, tgt)),
+              "batch+draws %.2f us" % graph_time(lambda: st.sample(B, step_draws=(S, N, 1.0, 0.0))),
+              "batch only %.2f us" % graph_time(lambda: st.sample(B)),
+              "draws only %.2f us" % graph_time(lambda: D.step_draws(B, S, N, 1.0, 0.0, dev)), flush=True)
 
 
 if __name__ == "__main__":
