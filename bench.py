@@ -559,7 +559,9 @@ def main():
         hp_ = system_.hp
         kw = {} if a.sync_in_graph is None else {"sync_in_graph": bool(a.sync_in_graph)}
         from nerf_pl_amd.system import _HipGraphBackend
-        src = (lambda: store_.sample(B, step_draws=(hp_.N_samples, hp_.N_importance, hp_.perturb, hp_.noise_std))) if in_graph else None
+        # ... and packs both models' weight images in that same launch (nerfhip_train_prologue): the step's whole prologue is one node
+        pk = (system_.models, system_.models[0].mlp_dtype) if system_.fused_train_step else None
+        src = (lambda: store_.sample(B, step_draws=(hp_.N_samples, hp_.N_importance, hp_.perturb, hp_.noise_std), pack_models=pk)) if in_graph else None
         st = {"graphed": GraphedTrainStep(system_, opt_, sync_, warmup=3, batch_source=src, backend=_HipGraphBackend(keep_graph=True), **kw)
               if not a.no_graph else None}
 
@@ -794,8 +796,8 @@ def main():
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if dist is not None and a.mode == "train" else ""),
                        "step_form": (None if a.mode != "train" else
                                      "modular autograd graph (render_rays -> MSELoss), separate Adam launch" if a.modular_step else
-                                     "fused node: batch + draws in one launch, coarse depths in the MLP prologue, composite+loss-gradient+composite-backward "
-                                     "(+ fine depths | + loss) per pass, one pack / dW / reduce launch for both models"
+                                     "fused node: batch + draws + both weight packs in one launch, coarse depths in the MLP prologue, composite+loss-gradient+"
+                                     "composite-backward (+ fine depths | + loss) per pass, one chain / dW / reduce launch for both models"
                                      + (", Adam applied inside the reduce kernel" if system.fuse_adam else ", separate Adam launch")),
                        "rccl_nranks": rccl_nranks,
                        "capture_fallback": (getattr(state["graphed"], "capture_fallback", None) if a.mode == "train" else None),

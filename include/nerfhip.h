@@ -347,6 +347,14 @@ uint64_t nerfhip_torch_draw_increment(int64_t numel, int max_blocks);
 int nerfhip_torch_draws(const nerfhip_draw* draws_host, int n_draws, const nerfhip_ray_batch* batch_host, uint64_t seed,
                         uint64_t offset, uint64_t* state, int max_blocks, uint64_t* increment_host, nerfhip_stream_t stream);
 
+/* The prologue of a training step in ONE launch: nerfhip_torch_draws (same arguments: the batch, its rays, the step's draws) and
+ * nerfhip_mlp_pack_weights_train_multi (same arguments: both images of n_models models) — the two jobs of the step that depend
+ * only on the generator state and on the parameters.  Same device code as the two launches, same results.                     */
+int nerfhip_train_prologue(const nerfhip_draw* draws_host, int n_draws, const nerfhip_ray_batch* batch_host, uint64_t seed,
+                           uint64_t offset, uint64_t* state, int max_blocks, uint64_t* increment_host,
+                           const float* const* weights_host, const float* const* biases_host, void* const* packed_host,
+                           void* const* packed_bwd_host, int n_models, int dtype, nerfhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

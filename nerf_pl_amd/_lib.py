@@ -81,6 +81,9 @@ SIGNATURES = {
     "nerfhip_torch_draw_increment": [_i64, _int],
     "nerfhip_torch_draws": [_c_void_p, _int, _c_void_p, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _int,
                             ctypes.POINTER(ctypes.c_uint64), _c_void_p],
+    "nerfhip_train_prologue": [_c_void_p, _int, _c_void_p, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _int,
+                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
     "nerfhip_mlp_dw_workspace_bytes_multi": [ctypes.POINTER(_i64), _int, _int],
     "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,

@@ -737,9 +737,11 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
     hipStream_t s = (hipStream_t)stream;
     const dim3 rgrid(8 * (nerfhip::mlp::kDwMaxXTiles + 1), (unsigned)jt.njobs);
     const bool do_chain = phases & 1, do_dw = phases & 2, do_reduce = phases & 4;
-    if (do_chain)
-        for (int m = 0; m < n_models; ++m) nerfhip::launch_bwd_chain(g_out_host[m], g_scale, out_host[m], n_host[m], packed_bwd_host[m], acts_host[m], dys_host[m], dtype,
-                                                                   act_tiles(n_host[m], dtype), s);
+    if (do_chain) {                                 // ONE launch for the chains of all models (fine first: the long one leads)
+        int64_t tiles[nerfhip::kDwMaxModels];
+        for (int m = 0; m < n_models; ++m) tiles[m] = act_tiles(n_host[m], dtype);
+        nerfhip::launch_bwd_chain(n_models, g_out_host, g_scale, out_host, n_host, packed_bwd_host, acts_host, dys_host, dtype, tiles, s);
+    }
     if (do_dw) {
         if (dtype == NERFHIP_BF16_F8)
             hipLaunchKernelGGL(nerfhip::mlp_bwd_dw_f8_kernel, dim3(nwg), dim3(512), 0, s, jt, (float*)dw_workspace);

@@ -348,9 +348,17 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
 
 template <int PREC, bool F8>
 __global__ __launch_bounds__(BwdTraits<PREC>::NW * 64, BwdTraits<PREC>::WPS)
-void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restrict__ g_scale, const float* __restrict__ out,
-                          int64_t n, const uint8_t* __restrict__ packed_bwd, const uint8_t* __restrict__ acts_base,
-                          uint8_t* __restrict__ dys_base) {
+void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
+    // ONE launch runs the chains of up to two models (a training step's fine and coarse network): the first A.blocks0 workgroups
+    // belong to model 0, the rest to model 1 — wave-uniform selects of the per-model pointers, nothing else changes
+    const int mdl = ((int)blockIdx.x >= A.blocks0) ? 1 : 0;
+    const unsigned wg = blockIdx.x - (mdl ? (unsigned)A.blocks0 : 0u);
+    const float* __restrict__ g_out = mdl ? A.g_out[1] : A.g_out[0];
+    const float* __restrict__ out = mdl ? A.out[1] : A.out[0];
+    const int64_t n = mdl ? A.n[1] : A.n[0];
+    const uint8_t* __restrict__ packed_bwd = mdl ? A.packed_bwd[1] : A.packed_bwd[0];
+    const uint8_t* __restrict__ acts_base = mdl ? A.acts[1] : A.acts[0];
+    uint8_t* __restrict__ dys_base = mdl ? A.dys[1] : A.dys[0];
     static_assert(!F8 || PREC == NERFHIP_BF16, "fp8 storage is a bf16-compute mode");
     using Slab = typename BwdTraits<PREC>::Slab;
     constexpr int kActTile = F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC);
@@ -361,7 +369,7 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    const int64_t tile = (int64_t)wg * NW + wave;
     const int64_t p = tile * 32 + (lane & 31);
     const bool valid = p < n;
     const int64_t pc = valid ? p : n - 1;
@@ -498,16 +506,24 @@ void mlp_bwd_chain_kernel(const float* __restrict__ g_out, const float* __restri
 }  // namespace nerfhip
 
 namespace nerfhip {
-void launch_bwd_chain(const float* g_out, const float* g_scale, const float* out, int64_t n, const void* packed_bwd,
-                      const void* acts, void* dys, int dtype, int64_t tiles, hipStream_t s) {
+void launch_bwd_chain(int n_models, const float* const* g_out, const float* g_scale, const float* const* out, const int64_t* n,
+                      const void* const* packed_bwd, const void* const* acts, void* const* dys, int dtype, const int64_t* tiles,
+                      hipStream_t s) {
+    const int wpw = (dtype == NERFHIP_F32) ? 4 : 8;                 // waves (32-point tiles) per workgroup
+    BwdChainArgs A;
+    unsigned blocks = 0;
+    for (int m = 0; m < 2; ++m) {
+        const int mm = m < n_models ? m : 0;
+        A.g_out[m] = g_out[mm]; A.out[m] = out[mm]; A.n[m] = n[mm];
+        A.packed_bwd[m] = (const uint8_t*)packed_bwd[mm]; A.acts[m] = (const uint8_t*)acts[mm]; A.dys[m] = (uint8_t*)dys[mm];
+        if (m == 0) A.blocks0 = (int)(tiles[0] / wpw);
+        if (m < n_models) blocks += (unsigned)(tiles[m] / wpw);
+    }
     if (dtype == NERFHIP_BF16_F8)
-        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, g_scale, out,
-                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_BF16, true>), dim3(blocks), dim3(512), 0, s, A, g_scale);
     else if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3((unsigned)(tiles / 8)), dim3(512), 0, s, g_out, g_scale,
-                           out, n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_BF16, false>), dim3(blocks), dim3(512), 0, s, A, g_scale);
     else
-        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3((unsigned)(tiles / 4)), dim3(256), 0, s, g_out, g_scale, out,
-                           n, (const uint8_t*)packed_bwd, (const uint8_t*)acts, (uint8_t*)dys);
+        hipLaunchKernelGGL((mlp_bwd_chain_kernel<NERFHIP_F32, false>), dim3(blocks), dim3(256), 0, s, A, g_scale);
 }
 }  // namespace nerfhip

@@ -30,12 +30,6 @@ __global__ __launch_bounds__(64) void mlp_pack_train_kernel(ParamTable P, uint8_
 }
 
 // the same for up to kPackMaxModels models in ONE launch (blockIdx.y = model): a training step's coarse and fine network
-constexpr int kPackMaxModels = 4;
-struct MultiPackTable {
-    ParamTable P[kPackMaxModels];
-    uint8_t* packed[kPackMaxModels];
-    uint8_t* packed_bwd[kPackMaxModels];
-};
 template <int PREC>
 __global__ __launch_bounds__(64) void mlp_pack_train_multi_kernel(MultiPackTable T) {
     const int nf = mlp::padded_pieces(PREC);

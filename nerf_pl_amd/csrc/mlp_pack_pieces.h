@@ -11,6 +11,13 @@ struct ParamTable {
     const float* w[12];
     const float* b[12];
 };
+// several models per launch (a training step's coarse and fine network)
+constexpr int kPackMaxModels = 4;
+struct MultiPackTable {
+    ParamTable P[kPackMaxModels];
+    uint8_t* packed[kPackMaxModels];
+    uint8_t* packed_bwd[kPackMaxModels];
+};
 
 template <int PREC>
 __device__ __forceinline__ uint4 pack_fwd_piece(const ParamTable& P, int g, int lane) {

@@ -15,6 +15,13 @@ __device__ __forceinline__ float linspace01(int i, int S) {
     return __builtin_fmaf(-step, (float)(S - 1 - i), 1.0f);
 }
 
+// linspace01 with the step formed once by the caller (three samples share it)
+__device__ __forceinline__ float linspace01_step(int i, int S, float step) {
+    if (S <= 1) return 0.0f;
+    if (i < S / 2) return nh_mul(step, (float)i);
+    return __builtin_fmaf(-step, (float)(S - 1 - i), 1.0f);
+}
+
 __device__ __forceinline__ float coarse_z_raw(float near, float far, int i, int S, int use_disp) {
     const float t = linspace01(i, S);
     const float omt = nh_sub(1.0f, t);
@@ -24,12 +31,21 @@ __device__ __forceinline__ float coarse_z_raw(float near, float far, int i, int 
 }
 
 // z of sample i of a ray with bounds (near, far): linear in depth or disparity (:189-193) and, when perturb > 0, jittered
-// between the mid-points to its neighbours with the caller's U[0,1) draw `prand` (:197-204)
+// between the mid-points to its neighbours with the caller's U[0,1) draw `prand` (:197-204).  Same expressions as coarse_z_raw
+// for samples i-1, i, i+1 with the shared terms (step, 1/near, 1/far) formed once: the divisions are IEEE-correct sequences of
+// ~40 instructions each, and this runs inside the MLP kernels' prologue (code bytes against a 64 KiB instruction cache).
 __device__ __forceinline__ float coarse_z_sample(float near, float far, int i, int S, int use_disp, float perturb, float prand) {
-    float zi = coarse_z_raw(near, far, i, S, use_disp);
+    const float step = (S > 1) ? nh_div(1.0f, (float)(S - 1)) : 0.0f;
+    const float bn = use_disp ? nh_div(1.0f, near) : near, bf = use_disp ? nh_div(1.0f, far) : far;
+    auto raw = [&](int k) {
+        const float t = linspace01_step(k, S, step);
+        const float v = nh_add(nh_mul(bn, nh_sub(1.0f, t)), nh_mul(bf, t));
+        return use_disp ? nh_div(1.0f, v) : v;
+    };
+    float zi = raw(i);
     if (perturb > 0.0f) {
-        const float zl = (i > 0) ? coarse_z_raw(near, far, i - 1, S, use_disp) : zi;
-        const float zr = (i < S - 1) ? coarse_z_raw(near, far, i + 1, S, use_disp) : zi;
+        const float zl = (i > 0) ? raw(i - 1) : zi;
+        const float zr = (i < S - 1) ? raw(i + 1) : zi;
         const float lower = (i > 0) ? nh_mul(0.5f, nh_add(zl, zi)) : zi;
         const float upper = (i < S - 1) ? nh_mul(0.5f, nh_add(zi, zr)) : zi;
         const float pr = nh_mul(perturb, prand);

@@ -110,12 +110,14 @@ def increment(numel, device):
     return int(_lib.load().nerfhip_torch_draw_increment(int(numel), max_blocks(device)))
 
 
-def draws(specs, device, generator=None, batch=None):
+def draws(specs, device, generator=None, batch=None, pack=None):
     """specs: [("rand", shape) | ("randn", shape) | ("randint", shape, high)], at most 6, each optionally followed by False =
     "nobody reads this draw" — returns the tensors the torch calls `torch.rand(*shape, device=device)`, ... would return IN THIS
     ORDER for `generator` (default: the device's default generator; None for the unread ones), which is advanced exactly as by
     those calls.  batch: an _lib.RayBatch for specs[0] (a randint over a RayStore's pixel ids): the drawn ids become rays / rgbs
-    in the same launch (rays.RayStore.sample) and are themselves not stored when specs[0] is marked unread."""
+    in the same launch (rays.RayStore.sample) and are themselves not stored when specs[0] is marked unread.
+    pack = (models, mlp_dtype): the launch also packs those models' weight images (nerfhip_train_prologue: the whole prologue of
+    a training step in one launch); the buffers are the models' own (ops.pack_models_train's)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.NerfHipError("nerf_pl_amd.draws runs on MI355X only (no CPU fallback); use torch.rand / randn on CPU tensors")
@@ -142,20 +144,33 @@ def draws(specs, device, generator=None, batch=None):
         inc = ctypes.c_uint64(0)
         bptr = ctypes.addressof(batch) if batch is not None else None
         lib = _lib.load()
+        if pack is not None:
+            from . import ops
+            models, dtype = pack
+            W, Bv, P, Pb, _bufs = ops.pack_tables(models, dtype)
+            tail = (W, Bv, P, Pb, len(models), ops.mlp_dtype_code(dtype), stream_ptr())
+
+            def launch(seed, off, state):
+                return lib.nerfhip_train_prologue(ctypes.addressof(arr), n, bptr, seed, off, state, max_blocks(device), ctypes.byref(inc),
+                                                  *tail)
+        else:
+            def launch(seed, off, state):
+                return lib.nerfhip_torch_draws(ctypes.addressof(arr), n, bptr, seed, off, state, max_blocks(device), ctypes.byref(inc),
+                                               stream_ptr())
         if torch.cuda.is_current_stream_capturing():
             st = _capture_state(device)
             if st is None or st.seed is None or (generator is not None and generator is not st.generator):
                 raise _lib.NerfHipError("draws() inside a hipGraph capture needs an armed GraphDrawState for its generator: capture "
                                         "under `with draws.capturing(state)` after `state.arm()` (system.GraphedTrainStep does both)")
-            check(lib.nerfhip_torch_draws(ctypes.addressof(arr), n, bptr, 0, 0, ptr(st.tensor), max_blocks(device), ctypes.byref(inc),
-                                          stream_ptr()), "nerfhip_torch_draws")
+            check(launch(0, 0, ptr(st.tensor)), "nerfhip_torch_draws")
             st.increment += int(inc.value)
         else:
             g = _generator(device, generator)
             seed, off = int(g.initial_seed()), int(g.get_offset())
-            check(lib.nerfhip_torch_draws(ctypes.addressof(arr), n, bptr, seed, off, None, max_blocks(device), ctypes.byref(inc),
-                                          stream_ptr()), "nerfhip_torch_draws")
+            check(launch(seed, off, None), "nerfhip_torch_draws")
             g.set_offset(off + int(inc.value))
+        if pack is not None:
+            ops.mark_packed(pack[0])
     return outs
 
 

@@ -38,7 +38,7 @@ def fusable(models, embeddings, loss_mod):
 class _TrainRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, rays, rgbs, *params):
-        models, S, use_disp, perturb, noise_std, N, white_back, adam, draws = cfg
+        models, S, use_disp, perturb, noise_std, N, white_back, adam, draws, packed = cfg
         rays = rays.float().contiguous()
         rgbs = rgbs.float().contiguous()
         B = rays.shape[0]
@@ -54,7 +54,11 @@ class _TrainRender(torch.autograd.Function):
         u = draws.get("u") if (N > 0 and perturb != 0) else None                           # :39
         if noise_std != 0 and (noise_c is None or (N > 0 and noise_f is None)):
             raise ValueError("render_rays_train: noise_std != 0 needs the noise draws")
-        packs = ops.pack_models_train(models, dtype)
+        # weight images: the batch's launch packed them (RayStore.sample(pack_models=...)) and the weights have not moved since —
+        # else ONE pack launch for both models here
+        fresh = (packed is not None and packed[0] == tuple(id(m) for m in models) and packed[1] == dtype
+                 and all(getattr(m, "_weights_serial", 0) == sr and getattr(m, "_packed_serial", None) == sr for m, sr in zip(models, packed[2])))
+        packs = [m.train_buffers(dtype, dev) for m in models] if fresh else ops.pack_models_train(models, dtype)
         # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`
         gscale = float(np.float32(2.0) / np.float32(3 * B))
         acts_c = ops.alloc_acts(B * S, dtype, dev)
@@ -103,6 +107,10 @@ class _TrainRender(torch.autograd.Function):
                 m._grad_ready_hook(m, flat)
                 grads.append((gw, gb, flat))
         else:
+            # Adam inside the reduce kernel only when these gradients ARE the step's gradients: with gradients already accumulated
+            # in p.grad (a second backward before the optimizer step) the update would be applied once per backward
+            if ctx.adam is not None and any(p.grad is not None for m in models for p in m.flat_params()):
+                ctx.adam = None
             adam = ctx.adam.handle(models) if ctx.adam is not None else None
             grads = ops.mlp_bwd_multi(entries, dtype, adam=adam, g_scale=g_scale)
             for m, g in zip(models, grads):
@@ -120,17 +128,18 @@ class _TrainRender(torch.autograd.Function):
 
 
 def render_rays_train(models, embeddings, rays, rgbs, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
-                      white_back=False, adam=None, draws=None):
+                      white_back=False, adam=None, draws=None, packed=None):
     """Training-mode `render_rays` + MSELoss + PSNR for one ray chunk.  Returns (results, loss, out3): `results` has the keys
     of render_rays (rendering.py:213-244; detached values: the only differentiable output is `loss`, whose backward produces
     the gradients of every parameter of `models`), out3 = [loss, psnr, mse] detached.
     adam: an optim.FlatAdam to apply inside the backward's reduce kernel (single-GPU steps; `optimizer.step()` then skips).
     draws: {'perturb_rand', 'noise_coarse', 'u', 'noise_fine'} tensors to consume instead of drawing (draws.step_specs names the
-    shapes): what RayStore.sample(step_draws=...) put into the batch, or the reference's recorded draws in a parity test."""
+    shapes): what RayStore.sample(step_draws=...) put into the batch, or the reference's recorded draws in a parity test.
+    packed: batch['packed'] of RayStore.sample(pack_models=...) — the weight images are already packed (checked for freshness)."""
     N = int(N_importance)
     use = list(models[:2]) if N > 0 else [models[0]]
     params = [p for m in use for p in m.flat_params()]
-    cfg = (use, int(N_samples), bool(use_disp), float(perturb), float(noise_std), N, bool(white_back), adam, draws)
+    cfg = (use, int(N_samples), bool(use_disp), float(perturb), float(noise_std), N, bool(white_back), adam, draws, packed)
     res = _TrainRender.apply(cfg, rays, rgbs, *params)
     loss, out3 = res[0], res[1]
     results = {'rgb_coarse': res[2], 'depth_coarse': res[3], 'opacity_coarse': res[4]}

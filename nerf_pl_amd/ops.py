@@ -562,9 +562,9 @@ def mlp_dx_embedded(dys, n, w_xyz1, w_xyz5, w_dir, dtype):
 
 
 # ------------------------------------------------------------------------------- several models per launch (training step)
-def pack_models_train(models, dtype):
-    """Forward + W^T images of every model in ONE launch (nerfhip_mlp_pack_weights_train_multi).  Returns [(packed, packed_bwd)]
-    in the models' cached buffers (NeRF.packed_weights_train's)."""
+def pack_tables(models, dtype):
+    """ctypes argument tables (weights, biases, forward images, W^T images) + the [(packed, packed_bwd)] buffers of `models` for
+    the multi-model pack entry points (nerfhip_mlp_pack_weights_train_multi, nerfhip_train_prologue)."""
     if not 1 <= len(models) <= 4:
         raise ValueError("pack_models_train packs 1..4 models")
     tabs, bufs = [], []
@@ -579,11 +579,23 @@ def pack_models_train(models, dtype):
     Bv = (ctypes.c_void_p * (12 * n))(*[t[1][i] for t in tabs for i in range(12)])
     P = (ctypes.c_void_p * n)(*[b[0].data_ptr() for b in bufs])
     Pb = (ctypes.c_void_p * n)(*[b[1].data_ptr() for b in bufs])
-    with torch.cuda.device(bufs[0][0].device):
-        check(_lib.load().nerfhip_mlp_pack_weights_train_multi(W, Bv, P, Pb, n, mlp_dtype_code(dtype), stream_ptr()),
-              "nerfhip_mlp_pack_weights_train_multi")
+    return W, Bv, P, Pb, bufs
+
+
+def mark_packed(models):
+    """the images just packed are those of the models' current weights (NeRF.check_pack_serial / train_step's freshness test)"""
     for m in models:
         m._packed_serial = getattr(m, "_weights_serial", 0)
+
+
+def pack_models_train(models, dtype):
+    """Forward + W^T images of every model in ONE launch (nerfhip_mlp_pack_weights_train_multi).  Returns [(packed, packed_bwd)]
+    in the models' cached buffers (NeRF.packed_weights_train's)."""
+    W, Bv, P, Pb, bufs = pack_tables(models, dtype)
+    with torch.cuda.device(bufs[0][0].device):
+        check(_lib.load().nerfhip_mlp_pack_weights_train_multi(W, Bv, P, Pb, len(models), mlp_dtype_code(dtype), stream_ptr()),
+              "nerfhip_mlp_pack_weights_train_multi")
+    mark_packed(models)
     return bufs
 
 

@@ -88,13 +88,16 @@ class RayStore:
     def __len__(self):
         return self.n_pixels
 
-    def sample(self, batch_size, generator=None, step_draws=None, return_ids=False):
+    def sample(self, batch_size, generator=None, step_draws=None, return_ids=False, pack_models=None):
         """One training batch in ONE launch (nerfhip_torch_draws with a ray batch): the pixel ids torch.randint(0, n_pixels,
         (batch_size,)) would draw from `generator` (default: the device's default generator, advanced identically), their rays
         and their colours.
         step_draws = (N_samples, N_importance, perturb, noise_std): the same launch also makes the draws the training step's
         render_rays will need (draws.step_specs: the reference's rand / randn calls, in its order, right after the batch's
-        randint on the generator's stream) and returns them under batch['draws'] for NeRFSystem.training_step."""
+        randint on the generator's stream) and returns them under batch['draws'] for NeRFSystem.training_step.
+        pack_models = (models, mlp_dtype): the launch also packs the weight images the step's MLP kernels stream
+        (nerfhip_train_prologue); batch['packed'] then names the models, and the fused training node skips its own pack launch
+        while the weights are still the ones packed here."""
         from . import draws as D
         dev = self.poses.device
         B = int(batch_size)
@@ -109,8 +112,10 @@ class RayStore:
             S, N, perturb, noise_std = step_draws
             keys, more = D.step_specs(B, int(S), int(N), float(perturb), float(noise_std))
             specs += more
-        outs = D.draws(specs, dev, generator, batch=rb)
+        outs = D.draws(specs, dev, generator, batch=rb, pack=pack_models)
         batch = {"rays": rays, "rgbs": rgbs}
+        if pack_models is not None:
+            batch["packed"] = (tuple(id(m) for m in pack_models[0]), pack_models[1], tuple(m._packed_serial for m in pack_models[0]))
         if return_ids:
             batch["ids"] = outs[0]
         if step_draws is not None:

@@ -125,8 +125,9 @@ class NeRFSystem(_Base):
             # a batch from RayStore.sample(step_draws=...) brings the step's random draws along (made in the launch that drew its
             # pixels); otherwise the fused node makes them itself — either way from torch's generator stream
             draws = batch.get('draws') if isinstance(batch, dict) else None
+            packed = batch.get('packed') if isinstance(batch, dict) else None
             results, loss, out3 = render_rays_train(self.models, self.embeddings, rays, rgbs, hp.N_samples, hp.use_disp, hp.perturb,
-                                                    hp.noise_std, hp.N_importance, self.white_back, adam=adam, draws=draws)
+                                                    hp.noise_std, hp.N_importance, self.white_back, adam=adam, draws=draws, packed=packed)
             self.loss.last = out3
             log['train/loss'] = loss
             psnr_ = out3[1]
@@ -144,12 +145,11 @@ class NeRFSystem(_Base):
 
     def _fused_adam_ok(self):
         """Adam inside the backward's reduce kernel is only the reference's step when nothing sits between the gradients and the
-        update: one rank (no all-reduce: with several ranks the update would use LOCAL gradients and the replicas diverge) and
-        no accumulated gradients (the update would be applied once per backward)."""
+        update: one rank (no all-reduce: with several ranks the update would use LOCAL gradients and the replicas diverge).  The
+        other condition — no accumulated gradients, or the update would be applied once per backward — is checked where it can be
+        known: in the backward itself (models/train_step.py)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return False
-        return all(p.grad is None for m in self.models for p in m.parameters())
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
     def _fused_step_ok(self, rays):
         if not (self.fused_train_step and torch.is_grad_enabled() and rays.is_cuda and rays.dim() == 2
@@ -285,7 +285,7 @@ class GraphedTrainStep:
 
     def _capture(self, batch):
         self.static_batch = {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()})
-                             for k, v in batch.items()} if batch is not None else None
+                             for k, v in batch.items() if torch.is_tensor(v) or isinstance(v, dict)} if batch is not None else None
         self.captured_lr = get_learning_rate(self.opt)
         self._arm_draws()
         self.static_out = None
@@ -338,7 +338,7 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self.static_batch[k].copy_(v, non_blocking=True)
-                else:
+                elif isinstance(v, dict):
                     for kk, vv in v.items():
                         self.static_batch[k][kk].copy_(vv, non_blocking=True)
         ds = self._draw_state

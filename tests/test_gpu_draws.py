@@ -116,6 +116,31 @@ def test_raystore_sample_is_randint_plus_sample_batch(dev, use_ndc):
     assert torch.equal(b2["rays"], rays) and torch.equal(b2["rgbs"], rgbs) and "draws" not in b2
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_step_prologue_is_the_batch_launch_plus_the_pack_launch(dev, dtype):
+    """nerfhip_train_prologue (RayStore.sample(..., pack_models=...)) == nerfhip_torch_draws + nerfhip_mlp_pack_weights_train_multi."""
+    from nerf_pl_amd import ops
+    st = _store(dev)
+    models = _models(dev, dtype)
+    B, S, N = 200, 64, 128
+    want_packs = [(a.clone(), b.clone()) for a, b in ops.pack_models_train(models, dtype)]
+    for m in models:
+        for buf in m.train_buffers(dtype, dev):
+            buf.zero_()
+    torch.manual_seed(3)
+    want = st.sample(B, step_draws=(S, N, 1.0, 1.0))
+    off = _gen(dev).get_offset()
+    torch.manual_seed(3)
+    got = st.sample(B, step_draws=(S, N, 1.0, 1.0), pack_models=(models, dtype))
+    assert _gen(dev).get_offset() == off and "packed" in got
+    assert torch.equal(got["rays"], want["rays"]) and torch.equal(got["rgbs"], want["rgbs"])
+    for k, v in want["draws"].items():
+        assert torch.equal(got["draws"][k], v), k
+    for m, (pf, pb) in zip(models, want_packs):
+        a, b = m.train_buffers(dtype, dev)
+        assert torch.equal(a, pf) and torch.equal(b, pb)
+
+
 def test_captured_draws_walk_the_generator_stream(dev):
     """A hipGraph holding one draw launch: replay k returns what the k-th eager call would, and torch's generator ends where k
     eager calls would leave it (GraphDrawState: device-resident offset advanced by the kernel, generator moved by the host)."""
