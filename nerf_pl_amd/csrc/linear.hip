@@ -393,7 +393,7 @@ using nerfhip::lin::vec_ok;
 
 static bool lin_dtype_ok(int dtype) { return dtype == NERFHIP_F32 || dtype == NERFHIP_BF16 || dtype == NERFHIP_BF16_F8; }
 static bool lin_act_ok(int act) { return act == NERFHIP_ACT_NONE || act == NERFHIP_ACT_RELU || act == NERFHIP_ACT_SIGMOID; }
-static bool ld_ok(int64_t ld) { return ld < (1 << 24); }      // 32-bit element offsets inside a tile
+static bool ld_ok(int64_t ld) { return ld > 0 && ld < (1 << 22); }   // a tile's element offsets r * ld + k (r < 256 rows) stay below 2^31 as 32-bit ints
 
 extern "C" int nerfhip_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                                   int64_t ldy, int64_t n, int n_in, int n_out, int act, int accumulate, int dtype,

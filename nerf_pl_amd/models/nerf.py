@@ -24,6 +24,17 @@ class Embedding(nn.Module):
             self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
         self.logscale = logscale
 
+    def _device_bands(self, device):
+        """`freq_bands` stays the plain CPU tensor the reference builds (nerf.py:16-19: not a buffer, not in the state_dict); its
+        copy on `device` is made once and kept — a pageable H2D copy per forward would synchronise the stream and cannot be
+        captured into a hipGraph."""
+        cache = self.__dict__.setdefault("_bands_on", {})
+        key = (device.type, device.index)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not self.freq_bands:
+            hit = cache[key] = (self.freq_bands, self.freq_bands.to(device, torch.float32).contiguous())
+        return hit[1]
+
     def forward(self, x):
         """x: (B, in_channels) -> (B, out_channels).  Reference: models/nerf.py:21-38.
         One HIP launch (K1 posenc) instead of 41; channel order identical to the reference."""
@@ -33,7 +44,7 @@ class Embedding(nn.Module):
         # logscale=True (the reference's only use, train.py:34-35): the kernel forms the bands 2^k itself; logscale=False: the
         # linspace bands of nerf.py:16-19 travel to the kernel as this module built them.  (The FUSED render_rays / NeRF path
         # encodes in-register with the logscale bands only: models/rendering._fusable.)
-        bands = None if self.logscale else self.freq_bands
+        bands = None if self.logscale else self._device_bands(x.device)
         out = ops.posenc(x.reshape(-1, self.in_channels).float(), self.N_freqs, bands=bands)
         return out.reshape(*lead, self.out_channels)
 

@@ -151,7 +151,31 @@ def _graphed_step_host_logic(rank, world):
             step2(b)
     flat2 = torch.cat([p.detach().reshape(-1) for p in sys2.parameters()])
     ok = ok and step2.capture_fallback is not None and step2._two_graphs() and step2.graph_opt is not None
-    return bool(ok and torch.allclose(flat2, rflat, rtol=1e-5, atol=1e-6))
+    ok = bool(ok and torch.allclose(flat2, rflat, rtol=1e-5, atol=1e-6))
+    # ... and a capture that fails on ONE rank only (rank 1), with its peer waiting in the collective the ranks use to agree on the
+    # branch (GradSync.agree_any): BOTH ranks must fall back — a rank replaying a captured all-reduce against a rank issuing an
+    # eager one would deadlock — and the replicas still follow the reference run
+    sys3 = _TinySystem()
+    opt3 = torch.optim.SGD(sys3.parameters(), lr=0.1)
+
+    class _Rank1CannotCapture(_RecordingBackend):
+        def capture(self, fn, share_pool_with=None):
+            if rank == 1 and getattr(fn, "__name__", "") == "<lambda>" and "_eager" in fn.__code__.co_names:
+                raise RuntimeError("capture failed on this rank only")
+            return super().capture(fn, share_pool_with)
+
+    step3 = GraphedTrainStep(sys3, opt3, grad_sync=parallel.GradSync(sys3.models), warmup=2, backend=_Rank1CannotCapture())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, b in enumerate(batches):
+            if i == 5:
+                for grp in opt3.param_groups:
+                    grp["lr"] = 0.05
+            step3(b)
+    flat3 = torch.cat([p.detach().reshape(-1) for p in sys3.parameters()])
+    ok = ok and step3.capture_fallback is not None and step3._two_graphs() and step3.graph_opt is not None
+    ok = ok and (("another rank" in step3.capture_fallback) == (rank != 1))
+    return bool(ok and torch.allclose(flat3, rflat, rtol=1e-5, atol=1e-6))
 
 
 def _worker(rank, world, port, n_rays, q):
@@ -161,9 +185,20 @@ def _worker(rank, world, port, n_rays, q):
     try:
         g = torch.Generator().manual_seed(7)
         rays = torch.rand(n_rays, 8, generator=g)
-        out = parallel.render_sharded(_fake_render, rays)
+        calls = {"n": 0}
+        real_gather = dist.all_gather_into_tensor
+
+        def counting_gather(*a, **kw):
+            calls["n"] += 1
+            return real_gather(*a, **kw)
+        dist.all_gather_into_tensor = counting_gather
+        try:
+            out = parallel.render_sharded(_fake_render, rays)
+        finally:
+            dist.all_gather_into_tensor = real_gather
         ref = _fake_render(rays)
-        ok_render = all(torch.equal(out[k], ref[k]) for k in ref)
+        # every key comes back whole, through ONE collective per image (rgb + depth + opacity packed as the columns of one buffer)
+        ok_render = all(torch.equal(out[k], ref[k]) for k in ref) and calls["n"] == 1
 
         # --- GradSync, generic branch: per-rank grads r+1 -> mean (world+1)/2
         m = _Tiny()
