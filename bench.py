@@ -308,6 +308,8 @@ def pmc_collect(a, note):
         P = P_f if g == grid(P_f) else (P_c if g == grid(P_c) else None)
         if base == "mlp_fwd_kernel" and P is not None and targs[2] != "true":
             key = "mlp_fwd_kernel" if targs[3] in ("0", "false") else "mlp_fwd_kernel<save>"
+        elif base == "mlp_bwd_chain_kernel" and g == grid(P_f) + grid(P_c):
+            key, P = "mlp_bwd_chain_kernel<merged>", P_f + P_c
         elif base == "mlp_bwd_chain_kernel" and P is not None:
             key = "mlp_bwd_chain_kernel"
         elif base in ("mlp_bwd_dw_kernel", "mlp_bwd_dw_f8_kernel"):
@@ -394,7 +396,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     def entry(name, tag, P, fn, flops, nbytes, what, key_name=None):
         todo.append((name, tag, P, fn, flops, nbytes, what, key_name or name))
 
-    keep, entries, dw_b, P_all = [], [], 0, 0
+    keep, entries, dw_b, P_all, chain_b = [], [], 0, 0, 0
     for tag, model, zz in (("fine pass", models[1], zf), ("coarse pass", models[0], z)):
         P = zz.numel()
         pk = model.packed_weights(dtype)
@@ -410,9 +412,11 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 12 * 592 * 4096
         entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
               FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
-        entry("mlp_bwd_chain_kernel", tag, P,
-              lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
-              FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read")
+        if not merged:
+            entry("mlp_bwd_chain_kernel", tag, P,
+                  lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
+                  FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read")
+        chain_b += dy_b + gate_b + 32 * P
         if not merged:
             entry("mlp_bwd_dw_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=2, workspace=ws),
@@ -430,6 +434,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         n_arr = (__import__("ctypes").c_int64 * 2)(*[e[1].numel() // 4 for e in entries])
         n_slabs = int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, 2, code)) // (4 * (8 * 10 * 64 * 16 + 8 * 64))
         ws_b = n_slabs * 592 * 4096 // 12        # average used blocks per partial slab (592 of a model's 12 jobs together)
+        entry("mlp_bwd_chain_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=1, workspace=wsm),
+              FLOP_PER_POINT_DX * P_all, chain_b, "dY of both models written once, ReLU gate words + g_out/out read", key_name="mlp_bwd_chain_kernel<merged>")
         entry("mlp_bwd_dw_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=2, workspace=wsm),
               FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>")
         entry("mlp_bwd_reduce_kernel", "both models in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=4, workspace=wsm),
@@ -440,7 +446,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     # also replayed TOGETHER, in the step's order, from one graph: `mix_us` = their time per round in the step's own clock mix.
     order = sorted(range(len(todo)), key=lambda i: (0 if "fwd" in todo[i][0] and "coarse" in todo[i][1] else
                                                     1 if "fwd" in todo[i][0] else
-                                                    2 if "chain" in todo[i][0] and "fine" in todo[i][1] else
+                                                    2 if "chain" in todo[i][0] and todo[i][1].startswith("fine") else
                                                     3 if "chain" in todo[i][0] else 4 if "dw" in todo[i][0] else 5, i))
     times = [event_time(todo[i][3], 12, graph=True) for i in order]
 

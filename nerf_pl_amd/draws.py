@@ -62,7 +62,8 @@ class GraphDrawState:
         self._upload()
 
     def _upload(self):
-        host = torch.tensor([self.seed, self.expect, 0, 0], dtype=torch.int64)
+        wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v          # uint64 bit patterns in an int64 tensor
+        host = torch.tensor([wrap(self.seed), wrap(self.expect), 0, 0], dtype=torch.int64)
         self.tensor.copy_(host)
 
     def before_replay(self):
