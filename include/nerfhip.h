@@ -232,6 +232,11 @@ typedef struct nerfhip_adam_fused {
     float lr, beta1, beta2, eps, weight_decay;
 } nerfhip_adam_fused;
 size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_host, int n_models, int dtype);
+/* The split plan of that launch (host logic only): splits_out[12 m + j] = workgroups of weight-gradient job j (the 12 parameter
+ * tensors in state_dict order, reference nerf.py:42-81) of model m; stage_kib_out (NULL ok) = KiB one ring iteration of the job
+ * reads.  bf16: workgroups are shared out so that iterations x (fixed cost + cost per KiB) is equal across jobs and models.
+ * Returns the number of workgroups (= partial slabs), < 0 on bad arguments.                                                      */
+int nerfhip_mlp_dw_plan(const int64_t* n_points_host, int n_models, int dtype, int* splits_out, int* stage_kib_out);
 int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const float* const* out_host, const int64_t* n_host,
                           const void* const* packed_bwd_host, const void* const* acts_host, void* const* dys_host,
                           void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host, int accumulate, int dtype,

@@ -85,6 +85,7 @@ SIGNATURES = {
                                ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
     "nerfhip_mlp_dw_workspace_bytes_multi": [ctypes.POINTER(_i64), _int, _int],
+    "nerfhip_mlp_dw_plan": [ctypes.POINTER(_i64), _int, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p, _c_void_p, _c_void_p],

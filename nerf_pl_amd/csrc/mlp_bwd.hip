@@ -61,6 +61,26 @@ __device__ __forceinline__ void glds16b_nt(const void* gsrc, unsigned lds_dst) {
 #endif
 }
 
+
+// s_waitcnt vmcnt(N) + s_barrier, N a compile-time constant of the (job class) loop it sits in
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+// wall clock in 10 ns ticks (s_memrealtime, 100 MHz) — the probe builds' time base
+__device__ __forceinline__ unsigned shader_cycles() { return (unsigned)__builtin_amdgcn_s_memrealtime(); }
+#ifndef NERFHIP_DW_PROBE
+#define NERFHIP_DW_PROBE 0       // debug builds: every wave of the dW kernels accumulates where its cycles go (tools/dw_probe.py)
+#endif
+#if NERFHIP_DW_PROBE
+__device__ unsigned g_dw_probe[1024 * 8 * 8];       // [workgroup][wave][iters, wait, barrier, issue, compute, total, job, depth]
+#endif
+
 // ================================================================================================
 // Phase B: weight gradients
 // ================================================================================================
@@ -83,6 +103,19 @@ struct DwJobTable {
 #ifndef NERFHIP_DW_DEPTH
 #define NERFHIP_DW_DEPTH 4
 #endif
+#ifndef NERFHIP_DW_RING_KB
+#define NERFHIP_DW_RING_KB 160   // bf16 dW ring: the whole LDS of a CU, cut into as many stages as the JOB's stage size allows (round 4)
+#endif
+#ifndef NERFHIP_DW_MAXDEPTH
+#define NERFHIP_DW_MAXDEPTH 12
+#endif
+#ifndef NERFHIP_DW_RD
+#define NERFHIP_DW_RD 5          // bf16: B fragments in flight (ring of RD, RD - 1 steps ahead of the MFMA)
+#endif
+#ifndef NERFHIP_DW_SPREAD
+#define NERFHIP_DW_SPREAD 1      // bf16: the next stage's DMAs issued between the current stage's MFMAs (0 = in one block after the barrier)
+#endif
+
 #ifndef NERFHIP_DW_WGS
 #define NERFHIP_DW_WGS 512       // target workgroup count of the fp32 dW launch (2 rounds of 256 CUs at 1 workgroup/CU)
 #endif
@@ -97,22 +130,34 @@ template <> struct DwTraits<NERFHIP_BF16> {
     static constexpr int DEPTH = NERFHIP_DW_DEPTH;   // ring stages
     static constexpr int MAXP = 36;          // max pieces per stage ((16 + 20) slabs)
     static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
+    static constexpr int RING_BYTES = NERFHIP_DW_RING_KB * 1024;
 };
 template <> struct DwTraits<NERFHIP_F32> {
     static constexpr int SPP = 2;
     static constexpr int DEPTH = 2;
     static constexpr int MAXP = 72;
     static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
+    static constexpr int RING_BYTES = DEPTH * STAGE_BYTES;
 };
+
+// ring stages of a job class whose stage is `pieces` KiB
+template <int PREC> NH_HD constexpr int dw_depth(int pieces) {
+    if (PREC != NERFHIP_BF16) return DwTraits<PREC>::DEPTH;
+    const int d = DwTraits<PREC>::RING_BYTES / (pieces * kPieceBytes);
+    return d > NERFHIP_DW_MAXDEPTH ? NERFHIP_DW_MAXDEPTH : d;
+}
 
 template <int PREC>
 __global__ __launch_bounds__(512, 2)
 void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
-    constexpr int SPP = DwTraits<PREC>::SPP, DEPTH = DwTraits<PREC>::DEPTH, MAXP = DwTraits<PREC>::MAXP;
-    constexpr int LPW = (MAXP + 7) / 8;                       // DMA instructions per wave per stage (padded)
-    constexpr int STAGE_BYTES = DwTraits<PREC>::STAGE_BYTES;
+    constexpr int SPP = DwTraits<PREC>::SPP;
     constexpr int SLAB_BYTES = SPP * kPieceBytes;
-    __shared__ __attribute__((aligned(1024))) char ring[DEPTH * STAGE_BYTES];
+    // The ring is sized in BYTES, not stages (round 4): a stage of a job is its own (dY + X slabs) KiB, and the ring holds as many
+    // of them as fit — bf16: 4 for the skip layer (36 KiB), 5 for the 256 x 256 layers, 6 / 8 / 8 / 12 for the dir / first / sigma /
+    // rgb jobs.  Job class = (X tiles, slabs per stage): the iteration loop exists once per class, so the stage count, the DMAs
+    // per wave and the counted vmcnt of its wait are compile-time constants.
+    constexpr int RING_BYTES = DwTraits<PREC>::RING_BYTES;
+    __shared__ __attribute__((aligned(1024))) char ring[RING_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -127,7 +172,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     const int n_ot = jb.dy_slabs / 2;
     const int n_xs = jb.x1_slabs + jb.x2_slabs;
     const int n_xt = n_xs / 2;
-    const int npieces = (jb.dy_slabs + n_xs) * SPP;
 #ifndef NERFHIP_DW_BLOCKED
 #define NERFHIP_DW_BLOCKED 1
 #endif
@@ -151,26 +195,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // slab and k-step strides are all multiples of 256 B.)
     const int dma_off_even = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + (lane >> 1)) * 16 : lane * 16;
     const int dma_off_odd = (PREC == NERFHIP_BF16) ? ((lane & 1) * 32 + ((lane ^ 8) >> 1)) * 16 : lane * 16;
-    auto issue_stage = [&](int64_t it) {
-        int64_t T = t_first + (it < my_tiles ? it : my_tiles - 1) * (NERFHIP_DW_BLOCKED ? 1 : nsplit);   // past the end: re-fetch
-        if (T >= ntiles) T = ntiles - 1;
-        const uint8_t* abase = acts_base + (size_t)T * act_tile_bytes(PREC);
-        const uint8_t* dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);
-        const unsigned slot = lds_base + (unsigned)((it % DEPTH) * STAGE_BYTES);
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            int pi = wave + 8 * i;
-            if (pi >= npieces) pi = npieces - 1;                            // duplicate DMA of the last piece
-            const int sl = pi / SPP, sub = pi % SPP;
-            const uint8_t* src;
-            if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
-            else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP);
-            else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
-            // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
-            // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
-            glds16b_nt(src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even), slot + (unsigned)(pi * kPieceBytes));
-        }
-    };
 
     f32x16 acc[kDwMaxXTiles];
 #pragma unroll
@@ -178,9 +202,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
     float dbacc = 0.0f;
-
-#pragma unroll
-    for (int s = 0; s < DEPTH - 1; ++s) issue_stage(s);
 
     // per-lane transposing-read geometry (bf16): 16-lane group g reads a [4 points][16 features] tile whose
     // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
@@ -193,20 +214,86 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // fp32 gather geometry: lane (m = l&31, k = l>>5): feature m -> slab m>>4, natural i = m&15 -> (h,j)
     const int m32 = lane & 31, kk = lane >> 5;
     const int f32_off = (m32 >> 4) * SLAB_BYTES + (slab_nat_h(m32 & 15) * 32) * 32 + slab_nat_j(m32 & 15) * 4;
+#if NERFHIP_DW_PROBE
+    unsigned pr_wait = 0, pr_bar = 0, pr_issue = 0, pr_comp = 0, pr_depth = 0;
+    const uint64_t pr_t00 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    // (one copy of the iteration loop per X-tile count, see mlp_bwd_dw_f8_kernel: straight-line X loop, next tile's LDS reads in
-    // flight under the current tile's MFMA)
-    auto run = [&](auto nxt_c) {
-        constexpr int NXT = decltype(nxt_c)::value;
+    // One copy of the iteration loop per job class (X tiles NXT, slabs per stage NSL): straight-line X loop with the next tiles'
+    // LDS reads in flight under the current tile's MFMA (see mlp_bwd_dw_f8_kernel), LPW = ceil(pieces / 8) DMAs per wave per stage
+    // (the surplus of the last round re-fetches the stage's last piece: every wave issues the SAME count, so one immediate
+    // vmcnt serves all), D ring stages.
+    auto run = [&](auto nxt_c, auto nsl_c) {
+        constexpr int NXT = decltype(nxt_c)::value, NSL = decltype(nsl_c)::value;
+        constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
+        constexpr int LPW = (NP + 7) / 8;
+        constexpr int D = dw_depth<PREC>(NP);
+        constexpr int STAGE = (PREC == NERFHIP_BF16) ? NP * kPieceBytes : DwTraits<PREC>::STAGE_BYTES;
+        static_assert(D >= 2 && D * STAGE <= RING_BYTES, "ring stages of this job class");
+        static_assert((D - 2) * LPW <= 63, "counted vmcnt");
+#if NERFHIP_DW_PROBE
+        pr_depth = D;
+#endif
+        int s_issue = 0, s_use = 0;               // ring slots of the next stage to fetch / to consume (wave-uniform, wrap at D)
+        // the stage a fetch goes to: tile block pointers + ring slot (wave-uniform), then one DMA per piece
+        const uint8_t* abase = nullptr;
+        const uint8_t* dbase = nullptr;
+        unsigned slot = 0;
+        auto next_stage = [&](int64_t it) {
+            int64_t T = t_first + (it < my_tiles ? it : my_tiles - 1) * (NERFHIP_DW_BLOCKED ? 1 : nsplit);   // past the end: re-fetch
+            if (T >= ntiles) T = ntiles - 1;
+            abase = acts_base + (size_t)T * act_tile_bytes(PREC);
+            dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);
+            slot = lds_base + (unsigned)(s_issue * STAGE);
+            s_issue = (s_issue + 1 == D) ? 0 : s_issue + 1;
+        };
+        auto issue_piece = [&](int i) {
+            int pi = wave + 8 * i;
+            if (pi >= NP) pi = NP - 1;                                          // duplicate DMA of the last piece
+            const int sl = pi / SPP, sub = pi % SPP;
+            const uint8_t* src;
+            if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
+            else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP);
+            else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
+            // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
+            // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
+            glds16b_nt(src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even), slot + (unsigned)(pi * kPieceBytes));
+        };
+        auto issue_stage = [&](int64_t it) {
+            next_stage(it);
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) issue_piece(i);
+        };
+        // bf16: the next stage's DMAs are issued one by one BETWEEN the MFMAs of the current stage (round 4).  Issued in one block at
+        // the top of the iteration — all 8 waves at once — they are 32-36 KiB through the CU's 64 B/clk texture-address path:
+        // tools/dw_probe.py measured 0.35 us of every 1.5 us iteration in that block, 0.27 us at the barrier behind it and no time
+        // at all waiting for data.  One DMA every DMA_STEP MFMAs hides the path's back-pressure under the other wave's MFMAs.
+        constexpr bool SPREAD = (PREC == NERFHIP_BF16) && NERFHIP_DW_SPREAD;
+        constexpr int DMA_STEP = (2 * NXT) / LPW > 0 ? (2 * NXT) / LPW : 1;
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) issue_stage(s);
         for (int64_t it = 0; it < my_tiles; ++it) {
-            // stage `it` landed (DEPTH-2 younger stages may still fly), everyone done with stage it-1
-            static_assert(PREC != NERFHIP_BF16 || LPW == 5, "counted vmcnt below assumes 5 DMAs per wave per stage");
-            if (PREC == NERFHIP_BF16 && DEPTH == 4)      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (PREC == NERFHIP_BF16 && DEPTH == 3) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else                                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            issue_stage(it + DEPTH - 1);
+            // stage `it` landed (D-2 younger stages may still fly), everyone done with stage it-1
+#if NERFHIP_DW_PROBE
+            const unsigned t0 = shader_cycles();
+            wait_vm<(PREC == NERFHIP_BF16) ? (D - 2) * LPW : 0>();
+            const unsigned t1 = shader_cycles();
+            asm volatile("s_barrier" ::: "memory");
+            const unsigned t2 = shader_cycles();
+            pr_wait += (t1 - t0) & 0xffffffffu;
+            pr_bar += (t2 - t1) & 0xffffffffu;
+#else
+            wait_vm_barrier<(PREC == NERFHIP_BF16) ? (D - 2) * LPW : 0>();
+#endif
+            if (SPREAD && wave < n_ot) next_stage(it + D - 1);
+            else issue_stage(it + D - 1);
+#if NERFHIP_DW_PROBE
+            const unsigned t3 = shader_cycles();
+            pr_issue += (t3 - t2) & 0xffffffffu;
+#endif
+            const char* st_base = ring + s_use * STAGE;
+            s_use = (s_use + 1 == D) ? 0 : s_use + 1;
             if (wave < n_ot) {
-                const char* st_base = ring + (it % DEPTH) * STAGE_BYTES;
                 const char* dy_base = st_base + (2 * wave) * SLAB_BYTES;
                 const char* x_base = st_base + jb.dy_slabs * SLAB_BYTES;
                 if constexpr (PREC == NERFHIP_BF16) {
@@ -216,25 +303,44 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                         f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s1));
                         return f.v;
                     };
+                    // The tile's 2 x NXT MFMAs (two 16-point k-steps q, X tiles x) as ONE software pipeline pinned with sched_barriers
+                    // (see mlp_bwd_dw_f8_kernel): the transposing reads of step m + RD - 1 are in flight when MFMA m issues, across
+                    // the k-step boundary too (round 4: the pipeline used to drain and refill at every k-step — two exposed LDS
+                    // round trips per ring stage with both waves of a SIMD in lock-step), and the bias sums (16 VALU per k-step)
+                    // sit behind the first MFMAs instead of in front of them.
+                    constexpr int RD = NERFHIP_DW_RD, NM = 2 * NXT;
+                    const bf16x8 a0 = load_frag(dy_base, 0);
+                    bf16x8 b[RD];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {                      // two 16-point k-steps per 32-point tile
-                        // software pipeline pinned with sched_barriers (see mlp_bwd_dw_f8_kernel): three tiles' reads ahead
-                        constexpr int RD = 4;
-                        const bf16x8 a = load_frag(dy_base, q);
-                        bf16x8 b[RD];
+                    for (int m = 0; m < RD - 1; ++m)
+                        if (m < NM) b[m] = load_frag(x_base + 2 * (m % NXT) * SLAB_BYTES, m / NXT);
+                    const bf16x8 a1 = load_frag(dy_base, 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int x = 0; x < RD - 1; ++x)
-                            if (x < NXT) b[x] = load_frag(x_base + 2 * x * SLAB_BYTES, q);
+                    for (int m = 0; m < NM; ++m) {
+                        const int x = m % NXT;
+                        if (m + RD - 1 < NM) b[(m + RD - 1) % RD] = load_frag(x_base + 2 * ((m + RD - 1) % NXT) * SLAB_BYTES, (m + RD - 1) / NXT);
                         __builtin_amdgcn_sched_barrier(0);
+                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m < NXT ? a0 : a1, b[m % RD], acc[x], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (m == 1) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) dbacc += (float)a[j];
-#pragma unroll
-                        for (int x = 0; x < NXT; ++x) {
-                            if (x + RD - 1 < NXT) b[(x + RD - 1) % RD] = load_frag(x_base + 2 * (x + RD - 1) * SLAB_BYTES, q);
-                            __builtin_amdgcn_sched_barrier(0);
-                            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[x % RD], acc[x], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int j = 0; j < 8; ++j) dbacc += (float)a0[j];
                         }
+                        if (m == NXT + 1 || (NXT == 1 && m == 1)) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) dbacc += (float)a1[j];
+                        }
+                        if constexpr (SPREAD) {
+                            if (m % DMA_STEP == DMA_STEP - 1 && m / DMA_STEP < LPW) {
+                                issue_piece(m / DMA_STEP);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                    if constexpr (SPREAD) {                            // (pieces the MFMA count did not reach)
+#pragma unroll
+                        for (int i = (2 * NXT) / DMA_STEP; i < LPW; ++i) issue_piece(i);
                     }
                 } else {
 #pragma unroll 4
@@ -250,31 +356,58 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     }
                 }
             }
+#if NERFHIP_DW_PROBE
+            pr_comp += (shader_cycles() - t3) & 0xffffffffu;
+#endif
         }
-    };
-    switch (n_xt) {
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 8: run(std::integral_constant<int, 8>{}); break;
-        case 9: run(std::integral_constant<int, 9>{}); break;
-        default: run(std::integral_constant<int, 10>{}); break;          // 10 = kDwMaxXTiles (the skip layer)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
-
-    if (wave < n_ot) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the look-ahead DMAs before exit
+        // this workgroup's partial sums: [dY tile][X tile][lane][16] + one bias row per dY tile
         float* sl = slabs + (size_t)blockIdx.x * kDwSlabFloats;
+        if (wave < n_ot) {
 #pragma unroll
-        for (int x = 0; x < kDwMaxXTiles; ++x) {
-            if (x < n_xt) {
+            for (int x = 0; x < NXT; ++x) {
                 float* dst = sl + ((size_t)(wave * kDwMaxXTiles + x) * 64 + lane) * 16;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
             }
+            sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
         }
-        sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
+    };
+    // job classes of mlp_layout.h kDwJobs: (X tiles, dY + X slabs per stage)
+    using std::integral_constant;
+    switch (n_xt) {
+        case 2: run(integral_constant<int, 2>{}, integral_constant<int, 20>{}); break;                 // first layer: 16 + 4
+        case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}); break;                 // rgb head: 2 + 8
+        case 8:
+            if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
+            else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head: 2 + 16
+            break;
+        case 9: run(integral_constant<int, 9>{}, integral_constant<int, 26>{}); break;                 // dir layer: 8 + 18
+        default: run(integral_constant<int, 10>{}, integral_constant<int, 36>{}); break;               // skip layer: 16 + 20 (kDwMaxXTiles)
     }
+#if NERFHIP_DW_PROBE
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned* pr = g_dw_probe + ((size_t)blockIdx.x * 8 + wave) * 8;
+        pr[0] = (unsigned)my_tiles; pr[1] = pr_wait; pr[2] = pr_bar; pr[3] = pr_issue; pr[4] = pr_comp;
+        pr[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - pr_t00);        // 100 MHz ticks
+        pr[6] = (unsigned)jid; pr[7] = pr_depth;
+    }
+#endif
 }
+
+// every job of mlp_layout.h has one of the kernel's classes (the switch above)
+NH_HD constexpr bool dw_job_has_class(const DwJob& j) {
+    const int nxt = (j.x1_slabs + j.x2_slabs) / 2, nsl = j.dy_slabs + j.x1_slabs + j.x2_slabs;
+    return (nxt == 2 && nsl == 20) || (nxt == 4 && nsl == 10) || (nxt == 8 && ((nsl == 32 && j.dy_slabs == 16) || (nsl == 18 && j.dy_slabs != 16))) ||
+           (nxt == 9 && nsl == 26) || (nxt == 10 && nsl == 36);
+}
+NH_HD constexpr bool dw_jobs_have_classes() {
+    for (int j = 0; j < kNumDwJobs; ++j)
+        if (!dw_job_has_class(kDwJobs[j])) return false;
+    return true;
+}
+static_assert(dw_jobs_have_classes(), "mlp_bwd_dw_kernel: a weight-gradient job without a compiled job class");
 
 // ================================================================================================
 // Phase B, fp8 storage (NERFHIP_BF16_F8): dW = dY^T X on v_mfma_scale_f32_32x32x64_f8f6f4
@@ -619,6 +752,17 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 #ifndef NERFHIP_DWF8_WGS
 #define NERFHIP_DWF8_WGS 256
 #endif
+// Round 4: with the inner loops pipelined (round 3) an iteration's time DOES follow its bytes — per-workgroup wall clocks of the
+// merged bf16 launch (tools/dw_probe.py, profiles/r04_dw_probe.txt): 0.69 / 0.91 / 0.82 / 1.05 / 1.40 / 1.63 us per iteration for
+// stages of 10 / 18 / 20 / 26 / 32 / 36 KiB, i.e. ~0.3 us + 35 ns per KiB.  With equal iteration counts the skip-layer workgroups
+// ran 626 us, the 256 x 256 layers 537 us and the rgb / first / sigma / dir jobs 280-430 us: the launch waited for 32 of its 256
+// workgroups while a quarter of the CUs idled for a third of it.  The plan now equalises iterations x (a + b x stage KiB).
+#ifndef NERFHIP_DW_COST_A
+#define NERFHIP_DW_COST_A 300
+#endif
+#ifndef NERFHIP_DW_COST_B
+#define NERFHIP_DW_COST_B 35
+#endif
 #ifndef NERFHIP_DW_MIN_ITERS
 #define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
 #endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
@@ -638,9 +782,19 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
     int64_t units[kDwMaxJobs];     // ring iterations of a job if it were one workgroup (f8: tile PAIRS)
     int64_t cap[kDwMaxJobs];
     int ns[kDwMaxJobs];
+    int64_t cost[kDwMaxJobs];      // time of one ring iteration of the job (ns): cost_a + cost_b x (dY + X slabs of a stage)
     int total = 0;
+    static const int cost_a = [] { const char* e = getenv("NERFHIP_DW_COST_A"); return e ? atoi(e) : -1; }();   // experiments only
+    static const int cost_b = [] { const char* e = getenv("NERFHIP_DW_COST_B"); return e ? atoi(e) : -1; }();
     for (int j = 0; j < njobs; ++j) {
         const int64_t tiles = act_tiles(n_points[j / kNumDwJobs], dtype);
+        const DwJob& jb = kDwJobs[j % kNumDwJobs];
+        // (the e4m3 launch keeps equal iteration counts: with the byte-weighted plan it measured 336 us against 254 us; the fp32
+        // launch has not been re-measured)
+        const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
+        const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
+        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs);
+        if (cost[j] < 1) cost[j] = 1;
         units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
         cap[j] = NERFHIP_DW_MIN_ITERS > 0 ? units[j] / NERFHIP_DW_MIN_ITERS : units[j];
         if (cap[j] > units[j]) cap[j] = units[j];
@@ -648,15 +802,15 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         ns[j] = 1;
         ++total;
     }
-    // greedy: the next workgroup goes to the job whose workgroups currently run the most iterations; ties go to the jobs with
-    // the most bytes per iteration (the 256 x 256 layers, jobs 1..8 of a model), then to the lower index
+    // greedy: the next workgroup goes to the job whose workgroups currently run the LONGEST (iterations x time per iteration);
+    // ties go to the jobs with the most bytes per iteration (the 256 x 256 layers, jobs 1..8 of a model), then to the lower index
     const int target = dw_target_wgs(dtype);
     while (total < target) {
         int best = -1;
         for (int j = 0; j < njobs; ++j) {
             if (ns[j] >= cap[j]) continue;
             if (best < 0) { best = j; continue; }
-            const int64_t a = units[j] * ns[best], b = units[best] * ns[j];          // units[j]/ns[j]  vs  units[best]/ns[best]
+            const int64_t a = units[j] * cost[j] * ns[best], b = units[best] * cost[best] * ns[j];   // time per workgroup of j vs best
             const int jj = j % kNumDwJobs, bb = best % kNumDwJobs;
             const bool j_big = jj >= 1 && jj <= 8, b_big = bb >= 1 && bb <= 8;
             if (a > b || (a == b && j_big && !b_big)) best = j;
@@ -693,6 +847,24 @@ extern "C" size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_h
     for (int m = 0; m < n_models; ++m)
         if (n_points_host[m] <= 0) return 0;
     return (size_t)dw_plan(n_points_host, n_models, dtype, nullptr) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+}
+
+// The split plan itself (host logic, no GPU): splits_out[12 m + j] = workgroups of weight-gradient job j of model m, stage_kib_out
+// (NULL ok) = KiB one ring iteration of that job moves.  Returns the number of workgroups.
+extern "C" int nerfhip_mlp_dw_plan(const int64_t* n_points_host, int n_models, int dtype, int* splits_out, int* stage_kib_out) {
+    if (!n_points_host || !splits_out || n_models < 1 || n_models > nerfhip::kDwMaxModels || !valid_dtype(dtype)) return NERFHIP_E_BADARG;
+    for (int m = 0; m < n_models; ++m)
+        if (n_points_host[m] <= 0) return NERFHIP_E_BADARG;
+    nerfhip::DwJobTable jt;
+    const int total = dw_plan(n_points_host, n_models, dtype, &jt);
+    for (int j = 0; j < n_models * nerfhip::mlp::kNumDwJobs; ++j) {
+        splits_out[j] = jt.nsplit[j];
+        if (stage_kib_out) {
+            const int slabs = jt.job[j].dy_slabs + jt.job[j].x1_slabs + jt.job[j].x2_slabs;
+            stage_kib_out[j] = dtype == NERFHIP_F32 ? 2 * slabs : slabs;            // (the e4m3 kernel moves TWO tiles of slabs / 2 KiB each)
+        }
+    }
+    return total;
 }
 
 extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const float* const* out_host,
@@ -758,6 +930,14 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
     }
     return nerfhip_launch_status();
 }
+
+#if NERFHIP_DW_PROBE
+// debug builds only (not part of include/nerfhip.h): the dW kernels' per-wave cycle accounts of the last launch
+extern "C" int nerfhip_debug_dw_probe(unsigned* host_dst, int n_words) {
+    if (!host_dst || n_words < 0 || n_words > 1024 * 8 * 8) return NERFHIP_E_BADARG;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nerfhip::g_dw_probe), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -100;
+}
+#endif
 
 extern "C" int nerfhip_mlp_bwd_phases(const float* g_out, const float* out, int64_t n, const void* packed_bwd, const void* acts,
                                       void* dys, void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host,

@@ -1,0 +1,76 @@
+"""CPU: the weight-gradient launch's split plan (host logic of csrc/mlp_bwd.hip `dw_plan`, exported as nerfhip_mlp_dw_plan).
+The launch computes dW_l = dY_l^T X_l for the 12 parameter tensors of each model (reference nerf.py:42-81 / autograd of
+nerf.py:100-124); a workgroup = (job, point range).  No compute calls: the plan is plain host arithmetic."""
+import ctypes
+
+import pytest
+
+F32, BF16, BF16_F8 = 0, 1, 2
+STAGE_KIB = [20, 32, 32, 32, 36, 32, 32, 32, 32, 26, 18, 10]        # dY + X slabs of a 32-point tile, per job (mlp_layout.h kDwJobs)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nerf_pl_amd import build
+    build.build(verbose=False)
+    from nerf_pl_amd import _lib
+    return _lib.load()
+
+
+def _plan(lib, points, dtype):
+    n = (ctypes.c_int64 * len(points))(*points)
+    sp = (ctypes.c_int * (12 * len(points)))()
+    kb = (ctypes.c_int * (12 * len(points)))()
+    total = lib.nerfhip_mlp_dw_plan(n, len(points), dtype, sp, kb)
+    return total, list(sp), list(kb)
+
+
+def test_benchmark_step_is_one_round_of_the_256_cus(lib):
+    """configs[2]: fine 1024 x 192 + coarse 1024 x 64 points in ONE launch."""
+    for dtype in (BF16, BF16_F8):
+        total, sp, kb = _plan(lib, [1024 * 192, 1024 * 64], dtype)
+        assert total == 256 == sum(sp)
+        assert min(sp) >= 1
+        assert kb == STAGE_KIB * 2
+    total, sp, kb = _plan(lib, [1024 * 192, 1024 * 64], F32)
+    assert total == 512 == sum(sp) and kb == [2 * k for k in STAGE_KIB] * 2
+
+
+def test_bf16_plan_equalises_time_not_iterations(lib):
+    """Round 4 (tools/dw_probe.py): an iteration of the bf16 kernel costs ~0.3 us + 35 ns per KiB of its stage, so equal
+    iteration counts left the skip-layer workgroups 17 % behind the 256 x 256 layers and the small heads idle for a third of the
+    launch.  The plan balances iterations x cost: the slowest workgroup within 12 % of the mean, the heads on fewer workgroups."""
+    pts = [1024 * 192, 1024 * 64]
+    total, sp, kb = _plan(lib, pts, BF16)
+    t = []
+    for j, (s, k) in enumerate(zip(sp, kb)):
+        tiles = pts[j // 12] // 32
+        t.append(-(-tiles // s) * (300 + 35 * k))
+    mean = sum(ti * s for ti, s in zip(t, sp)) / total
+    assert max(t) <= 1.12 * mean, (max(t), mean, sp)
+    assert sp[4] > sp[1] > sp[0] > sp[11]            # skip layer (36 KiB) > 256 x 256 (32) > first (20) > rgb head (10)
+    # the e4m3 kernel keeps equal iteration counts (measured: 254 us against 336 us with the byte-weighted plan)
+    total, sp8, _ = _plan(lib, pts, BF16_F8)
+    it = [-(-(pts[j // 12] // 64) // s) for j, s in enumerate(sp8)]
+    assert max(it) <= 1.25 * min(it), it
+
+
+def test_small_and_ragged_sizes(lib):
+    # fewer than 48 ring iterations per workgroup are never planned: a tiny batch gets one workgroup per job
+    total, sp, _ = _plan(lib, [100], BF16)
+    assert total == 12 and sp == [1] * 12
+    total, sp, _ = _plan(lib, [32 * 48 * 3 + 5], BF16)       # (padded to whole 256-point blocks)
+    assert all(1 <= s <= 3 for s in sp), sp
+    # one model with the benchmark's fine pass alone
+    total, sp, _ = _plan(lib, [1024 * 192], BF16_F8)
+    assert total == 256 and max(sp) - min(sp) <= 1
+
+
+def test_bad_arguments(lib):
+    sp = (ctypes.c_int * 24)()
+    n = (ctypes.c_int64 * 2)(1024, 0)
+    assert lib.nerfhip_mlp_dw_plan(n, 2, BF16, sp, None) < 0          # empty model
+    assert lib.nerfhip_mlp_dw_plan(n, 3, BF16, sp, None) < 0          # more models than one launch serves
+    assert lib.nerfhip_mlp_dw_plan(n, 1, 7, sp, None) < 0             # unknown dtype
+    assert lib.nerfhip_mlp_dw_plan(None, 1, BF16, sp, None) < 0
+    assert lib.nerfhip_mlp_dw_plan(n, 1, BF16, sp, None) == sum(sp[:12])
