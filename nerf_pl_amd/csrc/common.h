@@ -60,3 +60,7 @@ __device__ __forceinline__ double wave_incl_sum(double v, int lane) {
 }
 
 }  // namespace nerfhip
+
+#ifndef NERFHIP_STREAM_PROBE
+#define NERFHIP_STREAM_PROBE 0     // debug builds: the activation-saving forward / the backward chain record the time their waves spend at
+#endif                             // the weight ring's s_waitcnt and s_barrier (results of the launch are invalid; tools/stream_probe.py)

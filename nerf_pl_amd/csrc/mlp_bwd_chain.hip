@@ -100,6 +100,9 @@ struct BwdStream {
     int wave;
     int pending;   // stores issued since the last boundary (constant-folded; see mlp_fwd.hip)
     int pending_prev;
+#if NERFHIP_STREAM_PROBE
+    unsigned pr_wait = 0, pr_bar = 0, pr_n = 0;
+#endif
 
     __device__ __forceinline__ void issue_chunk(int c) const {
 #pragma unroll
@@ -121,13 +124,26 @@ struct BwdStream {
         const int n = (c + 1 < NCH ? LPW : 0) + pending + (NERFHIP_STORE_SLACK ? pending_prev : 0);
         pending_prev = pending;
         pending = 0;
-#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#if NERFHIP_STREAM_PROBE
+#define NH_WBAR
+        const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#else
+#define NH_WBAR "\n\ts_barrier"
+#endif
+#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" NH_WBAR ::: "memory"); break;
         switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {
             NH_WB(0) NH_WB(1) NH_WB(2) NH_WB(3) NH_WB(4) NH_WB(5) NH_WB(6) NH_WB(7) NH_WB(8)
             NH_WB(12) NH_WB(16) NH_WB(20) NH_WB(24) NH_WB(28) NH_WB(32) NH_WB(36) NH_WB(40) NH_WB(44) NH_WB(48)
-            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" NH_WBAR ::: "memory"); break;
         }
 #undef NH_WB
+#undef NH_WBAR
+#if NERFHIP_STREAM_PROBE
+        const unsigned t1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned t2 = (unsigned)__builtin_amdgcn_s_memrealtime();
+        pr_wait += t1 - t0; pr_bar += t2 - t1; pr_n += 1;
+#endif
         if (c + 2 < NCH) issue_chunk(c + 2);
     }
 };
@@ -366,6 +382,9 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
     constexpr int kDyTile = F8 ? f8_dy_tile_bytes() : kDySlabs * 64 * (int)sizeof(Slab);
     constexpr int NW = BwdTraits<PREC>::NW;
     __shared__ __attribute__((aligned(1024))) char ring[kSlots * kChunkBytes + NW * 64 * (int)sizeof(Slab)];      // W^T ring | sigma-slab stash
+#if NERFHIP_STREAM_PROBE
+    const uint64_t probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
@@ -500,6 +519,13 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) save_dy_pair(st.pending, dy_tile, dy_h(1) / 2 + q, ga[2 * q], ga[2 * q + 1], sb, lane);
     }
+#if NERFHIP_STREAM_PROBE
+    if (lane == 0) {                  // (overwrites the first dwords of the tile's dY block: probe builds only)
+        unsigned* pr = reinterpret_cast<unsigned*>(dy_tile);
+        pr[0] = st.pr_wait; pr[1] = st.pr_bar; pr[2] = st.pr_n;
+        pr[3] = (unsigned)(__builtin_amdgcn_s_memrealtime() - probe_t0);
+    }
+#endif
 }
 
 

@@ -103,6 +103,9 @@ struct WeightStream {
     int pending;             // vector-memory STORE instructions issued since the last boundary (SAVE variant).
                              // Straight-line code: the optimiser folds this to a constant at every boundary.
     int pending_prev;        // ... and in the interval before that
+#if NERFHIP_STREAM_PROBE
+    unsigned pr_wait = 0, pr_bar = 0, pr_n = 0;     // 10 ns ticks at the boundaries' s_waitcnt / s_barrier, boundaries passed
+#endif
 
     __device__ __forceinline__ void issue_piece(int c, int k) const {      // k-th of this wave's LPW pieces of chunk c
         const int piece = wave + k * NW;
@@ -147,7 +150,16 @@ struct WeightStream {
             const int n = (c + 1 < NCH ? LPW : 0) + pending + (NERFHIP_STORE_SLACK ? pending_prev : 0);
             pending_prev = pending;
             pending = 0;
+#if NERFHIP_STREAM_PROBE
+            const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+            wait_only(n);
+            const unsigned t1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+            asm volatile("s_barrier" ::: "memory");
+            const unsigned t2 = (unsigned)__builtin_amdgcn_s_memrealtime();
+            pr_wait += t1 - t0; pr_bar += t2 - t1; pr_n += 1;
+#else
             wait_barrier(n);
+#endif
         } else if (c + 1 < NCH) {
             if (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -156,6 +168,17 @@ struct WeightStream {
         }
         if (c + 2 < NCH) issue_chunk(c + 2);
     }
+#if NERFHIP_STREAM_PROBE
+    static __device__ __forceinline__ void wait_only(int n) {
+#define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {
+            NH_WB(0) NH_WB(1) NH_WB(2) NH_WB(3) NH_WB(4) NH_WB(5) NH_WB(6) NH_WB(7) NH_WB(8)
+            NH_WB(12) NH_WB(16) NH_WB(20) NH_WB(24) NH_WB(28) NH_WB(32) NH_WB(36) NH_WB(40) NH_WB(44) NH_WB(48)
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+#undef NH_WB
+    }
+#endif
     static __device__ __forceinline__ void wait_barrier(int n) {
 #define NH_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         switch (n < 0 ? 0 : (n > 48 ? 48 : (n <= 8 ? n : (n & ~3)))) {   // multiples of 4 above 8 (round DOWN = safe)
@@ -568,6 +591,9 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
 #if NERFHIP_CLOCK_PROBE
     const uint64_t probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
+#if NERFHIP_STREAM_PROBE
+    const uint64_t probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
@@ -752,6 +778,15 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
                 o.w = sigma_p;                                        // cat([rgb, sigma])   nerf.py:122
                 reinterpret_cast<float4*>(out)[po] = o;
             }
+#if NERFHIP_STREAM_PROBE
+            if constexpr (SAVE) {
+                if (lane_o == 0) {        // (overwrites the first dwords of the tile's xyz-encoding slab: probe builds only)
+                    unsigned* pr = reinterpret_cast<unsigned*>(tile_base);
+                    pr[0] = st.pr_wait; pr[1] = st.pr_bar; pr[2] = st.pr_n;
+                    pr[3] = (unsigned)(__builtin_amdgcn_s_memrealtime() - probe_t0);
+                }
+            }
+#endif
 #if NERFHIP_CLOCK_PROBE
             if constexpr (F8) {
                 if (lane_o == 0) {
