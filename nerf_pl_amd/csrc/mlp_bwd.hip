@@ -522,6 +522,10 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 
 #pragma unroll
     for (int s = 0; s < DEPTH - 1; ++s) issue_stage(s);
+#if NERFHIP_DW_PROBE
+    unsigned pr_wait = 0, pr_bar = 0, pr_issue = 0, pr_comp = 0;
+    const uint64_t pr_t00 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // per-lane read geometry: H = lane >> 5 (points 16H..16H+15 of each tile), s = slab of the pair, r = source row
     const int H = lane >> 5, sl = (lane >> 4) & 1, r = lane & 15;
@@ -541,10 +545,22 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         constexpr int NXT = decltype(nxt_c)::value;
         for (int64_t it = 0; it < my_pairs; ++it) {
             // stage `it` landed (DEPTH-2 younger stages of LPW + 1 DMAs may still fly), everyone done with stage it-1
-            if (DEPTH == 4)      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if NERFHIP_DW_PROBE
+            const unsigned t0 = shader_cycles();
+            wait_vm<(DEPTH - 2) * (LPW + 1)>();
+            const unsigned t1 = shader_cycles();
+            asm volatile("s_barrier" ::: "memory");
+            const unsigned t2 = shader_cycles();
+            pr_wait += t1 - t0;
+            pr_bar += t2 - t1;
+#else
+            wait_vm_barrier<(DEPTH - 2) * (LPW + 1)>();
+#endif
             issue_stage(it + DEPTH - 1);
+#if NERFHIP_DW_PROBE
+            const unsigned t3 = shader_cycles();
+            pr_issue += t3 - t2;
+#endif
             if (wave < n_ot) {
                 const char* st_base = ring + (it % DEPTH) * STAGE_BYTES + rd_off;
                 const char* sc_base = ring + DEPTH * STAGE_BYTES + ((it % DEPTH) * 8 + wave) * SCALE_BYTES + H * 64;
@@ -581,6 +597,9 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if NERFHIP_DW_PROBE
+            pr_comp += shader_cycles() - t3;
+#endif
         }
     };
     switch (n_xt) {
@@ -610,6 +629,14 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
         }
     }
+#if NERFHIP_DW_PROBE
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned* pr = g_dw_probe + ((size_t)blockIdx.x * 8 + wave) * 8;
+        pr[0] = (unsigned)my_pairs; pr[1] = pr_wait; pr[2] = pr_bar; pr[3] = pr_issue; pr[4] = pr_comp;
+        pr[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - pr_t00);        // 100 MHz ticks
+        pr[6] = (unsigned)jid; pr[7] = DEPTH;
+    }
+#endif
 }
 
 
@@ -757,15 +784,17 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 // stages of 10 / 18 / 20 / 26 / 32 / 36 KiB, i.e. ~0.3 us + 35 ns per KiB.  With equal iteration counts the skip-layer workgroups
 // ran 626 us, the 256 x 256 layers 537 us and the rgb / first / sigma / dir jobs 280-430 us: the launch waited for 32 of its 256
 // workgroups while a quarter of the CUs idled for a third of it.  The plan now equalises iterations x (a + b x stage KiB).
+// The cost model is deliberately the coarse linear one.  A table of the per-class costs measured under a balanced plan (0.72 / 0.95 /
+// 0.94 / 1.13 / 1.58 / 1.81 us per iteration for 10 / 18 / 20 / 26 / 32 / 36 KiB stages) makes every workgroup finish within 3 % of
+// the others (profiles/r04_dw_probe_bf16_table_plan.txt) and the launch SLOWER: 473-480 us against 455-458 us in the same call —
+// with the linear model the first-layer and dir-layer workgroups finish ~15 % early, and the bandwidth they release goes to the
+// 256 x 256 and skip-layer workgroups that end the launch, whose partial slabs then do not all land in the same microseconds.
 #ifndef NERFHIP_DW_COST_A
 #define NERFHIP_DW_COST_A 300
 #endif
 #ifndef NERFHIP_DW_COST_B
 #define NERFHIP_DW_COST_B 35
 #endif
-#ifndef NERFHIP_DW_MIN_ITERS
-#define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
-#endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
 static int dw_target_wgs(int dtype) {
     static const int env = [] {
         const char* e = getenv("NERFHIP_DW_WGS");            // experiments only
@@ -790,7 +819,7 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         const int64_t tiles = act_tiles(n_points[j / kNumDwJobs], dtype);
         const DwJob& jb = kDwJobs[j % kNumDwJobs];
         // (the e4m3 launch keeps equal iteration counts: with the byte-weighted plan it measured 336 us against 254 us; the fp32
-        // launch has not been re-measured)
+        // launch has not been re-measured.  NERFHIP_DW_COST_A / _B = a + b x KiB instead, for experiments)
         const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
         const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
         cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs);
