@@ -766,21 +766,21 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
     return (size_t)act_tiles(n_points, dtype) * nerfhip::mlp::kDySlabs * 64 * (dtype == NERFHIP_BF16 ? 16 : 32);
 }
 
-// The split plan: which workgroup = which (job, point range).  EQUAL ring-iteration counts per workgroup: under load every
-// workgroup completes one stage per (loaded HBM latency / stages in flight) whatever the stage's size, so a workgroup's time
-// follows its iteration count, not its bytes — splits in proportion to the jobs' bytes (5 to 18 slab pairs per tile) measured
-// 306 / 290 / 268 us at 512 / 768 / 1024 workgroups against 225-232 us for equal iteration counts (1024 x 192 points).
+// The split plan: which workgroup = which (job, point range).
+// Rounds 1-3 gave every workgroup the SAME number of ring iterations: until the inner loops were software-pipelined (round 3) an
+// iteration cost ten exposed LDS round trips whatever its bytes, and splits in proportion to the jobs' bytes measured 268-306 us
+// against 225-232 us (e4m3, 1024 x 192 points).  The e4m3 launch still plans that way; the bf16 launch — see below — no longer.
 // e4m3 kernel: ONE round of the 256 CUs (measured at 1024 x 192: 207-215 us vs 233-247 us for 384-768 workgroups, and half the
-// split-K partials for the reduce kernel: 23 -> 12.5 us); the bf16 kernel does not care (440 us either way), the fp32 one
-// prefers two rounds (2,882 vs 3,244 us).
-// Several models in one launch (a training step's fine + coarse network): the workgroups are shared out so that the iteration
-// counts stay equal ACROSS the models — a model with a third of the points gets a third of the splits per job — instead of a
-// second, short launch that cannot hide its pipeline fill (coarse pass alone: 0.49 of the HBM peak vs 0.62 for the fine pass).
+// split-K partials for the reduce kernel: 23 -> 12.5 us); bf16 one round too (every workgroup less is a 330 KB partial slab neither
+// written nor re-read), fp32 two rounds (2,882 vs 3,244 us).
+// Several models in one launch (a training step's fine + coarse network): the workgroups are shared out ACROSS the models — a model
+// with a third of the points gets a third of the splits per job — instead of a second, short launch that cannot hide its pipeline
+// fill (coarse pass alone: 0.49 of the HBM peak vs 0.62 for the fine pass).
 #ifndef NERFHIP_DWF8_WGS
 #define NERFHIP_DWF8_WGS 256
 #endif
 // Round 4: with the inner loops pipelined (round 3) an iteration's time DOES follow its bytes — per-workgroup wall clocks of the
-// merged bf16 launch (tools/dw_probe.py, profiles/r04_dw_probe.txt): 0.69 / 0.91 / 0.82 / 1.05 / 1.40 / 1.63 us per iteration for
+// merged bf16 launch (tools/dw_probe.py, profiles/r04_dw_probe_call14_block_issue.txt): 0.69 / 0.91 / 0.82 / 1.05 / 1.40 / 1.63 us per iteration for
 // stages of 10 / 18 / 20 / 26 / 32 / 36 KiB, i.e. ~0.3 us + 35 ns per KiB.  With equal iteration counts the skip-layer workgroups
 // ran 626 us, the 256 x 256 layers 537 us and the rgb / first / sigma / dir jobs 280-430 us: the launch waited for 32 of its 256
 // workgroups while a quarter of the CUs idled for a third of it.  The plan now equalises iterations x (a + b x stage KiB).
@@ -795,6 +795,9 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 #ifndef NERFHIP_DW_COST_B
 #define NERFHIP_DW_COST_B 35
 #endif
+#ifndef NERFHIP_DW_MIN_ITERS
+#define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
+#endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
 static int dw_target_wgs(int dtype) {
     static const int env = [] {
         const char* e = getenv("NERFHIP_DW_WGS");            // experiments only
