@@ -22,7 +22,7 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 done
-timeout 100 python tools/small_kernel_bench.py > $OUT/small_kernels.txt 2>&1; tail -2 $OUT/small_kernels.txt
-timeout 60 tools/probes/probe_mall.bin > $OUT/probe_mall.txt 2>&1
+[ -n "${SKIP_PROBES:-}" ] || { timeout 100 python tools/small_kernel_bench.py > $OUT/small_kernels.txt 2>&1; tail -2 $OUT/small_kernels.txt; }
+[ -n "${SKIP_PROBES:-}" ] || timeout 60 tools/probes/probe_mall.bin > $OUT/probe_mall.txt 2>&1
 [ -n "${SKIP_TESTS:-}" ] || ( time python -m pytest tests -q -m gpu --durations=8 2>&1 | grep -E "passed|failed|FAILED|Error|^[0-9.]+s " | tail -14 ) 2>&1 | tee $OUT/pytest_gpu.txt
 ls $OUT
