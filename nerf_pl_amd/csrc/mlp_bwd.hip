@@ -62,6 +62,19 @@ __device__ __forceinline__ void glds16b_nt(const void* gsrc, unsigned lds_dst) {
 }
 
 
+// the same for the lanes of `mask` only (wave-uniform): the LDS image is lane-linear, so the other lanes' 16-byte units are simply not
+// fetched; the instruction still counts once in vmcnt
+__device__ __forceinline__ void glds16b_nt_masked(const void* gsrc, unsigned lds_dst, unsigned long long mask) {
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %4\n\tglobal_load_lds_dwordx4 %2, off nt\n\t"
+        "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(keep_exec)
+        : "v"(gsrc), "s"(lds_dst), "s"(mask)
+        : "memory");
+}
+
 // s_waitcnt vmcnt(N) + s_barrier, N a compile-time constant of the (job class) loop it sits in
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
@@ -107,6 +120,9 @@ struct DwJobTable {
 #endif
 #ifndef NERFHIP_DW_MAXDEPTH
 #define NERFHIP_DW_MAXDEPTH 12
+#endif
+#ifndef NERFHIP_DW_SHARE_LAST
+#define NERFHIP_DW_SHARE_LAST 1  // bf16: the waves share a stage's last REM < 8 pieces under EXEC masks (0 = the surplus waves re-fetch the last piece)
 #endif
 #ifndef NERFHIP_DW_RD
 #define NERFHIP_DW_RD 5          // bf16: B fragments in flight (ring of RD, RD - 1 steps ahead of the MFMA)
@@ -246,9 +262,19 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             slot = lds_base + (unsigned)(s_issue * STAGE);
             s_issue = (s_issue + 1 == D) ? 0 : s_issue + 1;
         };
+        // The last of a wave's LPW DMAs per stage: when the stage has REM = NP mod 8 pieces left for it (4 or 2 in the bf16 classes), the
+        // 8 waves SHARE them — 8 / REM waves per piece, each fetching its 64 REM / 8 lanes' units under an EXEC mask — instead of
+        // 8 - REM waves re-fetching the stage's last piece: every wave still issues the same count (one immediate vmcnt), and no byte
+        // is fetched twice (round 4: the re-fetches were up to a quarter of a small job's DMAs, and nt loads do not stay in L2).
+        constexpr int REM = NP % 8;
+        constexpr bool SHARE_LAST = (PREC == NERFHIP_BF16) && NERFHIP_DW_SHARE_LAST && (REM == 4 || REM == 2);
+        const int share_piece = NP - REM + (SHARE_LAST ? (wave * REM) / 8 : 0);
+        const unsigned long long share_mask = REM == 4 ? (0xffffffffull << (32 * (wave & 1))) : (0xffffull << (16 * (wave & 3)));
         auto issue_piece = [&](int i) {
             int pi = wave + 8 * i;
-            if (pi >= NP) pi = NP - 1;                                          // duplicate DMA of the last piece
+            const bool shared = SHARE_LAST && i == LPW - 1;
+            if (shared) pi = share_piece;
+            if (pi >= NP) pi = NP - 1;                                          // (classes without sharing) duplicate DMA of the last piece
             const int sl = pi / SPP, sub = pi % SPP;
             const uint8_t* src;
             if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
@@ -256,7 +282,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
             // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
             // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
-            glds16b_nt(src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even), slot + (unsigned)(pi * kPieceBytes));
+            const uint8_t* g = src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even);
+            if (shared) glds16b_nt_masked(g, slot + (unsigned)(pi * kPieceBytes), share_mask);
+            else glds16b_nt(g, slot + (unsigned)(pi * kPieceBytes));
         };
         auto issue_stage = [&](int64_t it) {
             next_stage(it);
