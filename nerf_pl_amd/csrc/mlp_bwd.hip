@@ -110,7 +110,18 @@ struct DwJobTable {
     const uint8_t* dys[kDwMaxJobs];    // dY slabs of the job's model
     int64_t ntiles[kDwMaxJobs];        // 32-point wave tiles of the job's model
     int njobs;
+    // bf16 (round 4): the sigma head's job has no workgroups of its own — its X is the final layer's X (h8: 16 slabs per tile that the
+    // launch used to read twice, 134 MB of its 2.87 GB) — so the FINAL layer's workgroups also form dW_sigma: fold_of[sigma job] = the
+    // final job's index (its partial slabs hold the sigma partials in the tile column it does not use), -1 everywhere else.
+    int fold_of[kDwMaxJobs];
 };
+constexpr int kDwJobFinal = 8, kDwJobSigma = 10;       // indices in mlp_layout.h kDwJobs
+static_assert(kDwJobs[kDwJobFinal].x1_off == kDwJobs[kDwJobSigma].x1_off && kDwJobs[kDwJobFinal].x1_slabs == 16 &&
+              kDwJobs[kDwJobSigma].x1_slabs == 16 && kDwJobs[kDwJobSigma].dy_slabs == 2 && kDwJobs[kDwJobFinal].x2_slabs == 0 &&
+              kDwJobs[kDwJobSigma].x2_slabs == 0, "the sigma head and the final layer read the same X section");
+constexpr int kDwFoldCol = 8;          // tile column of the final job's partial slab that holds the sigma partials (it uses columns 0..7)
+constexpr int kDwFoldBiasCol = 9;      // ... and the first 64 floats of (row 0, this column) its bias partial
+static_assert(kDwFoldBiasCol < kDwMaxXTiles, "fold columns inside the slab");
 #ifndef NERFHIP_DW_DEPTH
 #define NERFHIP_DW_DEPTH 4
 #endif
@@ -217,6 +228,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
     float dbacc = 0.0f;
+    [[maybe_unused]] f32x16 acc_sig;                  // (folded sigma head, class (8, 34) only)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_sig[r] = 0.0f;
+    [[maybe_unused]] float dbacc_sig = 0.0f;
 
     // per-lane transposing-read geometry (bf16): 16-lane group g reads a [4 points][16 features] tile whose
     // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
@@ -240,6 +255,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // vmcnt serves all), D ring stages.
     auto run = [&](auto nxt_c, auto nsl_c) {
         constexpr int NXT = decltype(nxt_c)::value, NSL = decltype(nsl_c)::value;
+        // class (8, 34) = the final layer with the sigma head folded in: stage = [dY_feat 16][h8 16][dY_sigma 2] slabs; every wave
+        // adds ONE MFMA per k-step, dY_sigma x (X tile `wave`), into an accumulator of its own
+        constexpr bool FOLD = (PREC == NERFHIP_BF16) && NXT == 8 && NSL == 34;
         constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
         constexpr int LPW = (NP + 7) / 8;
         constexpr int D = dw_depth<PREC>(NP);
@@ -277,7 +295,8 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             if (pi >= NP) pi = NP - 1;                                          // (classes without sharing) duplicate DMA of the last piece
             const int sl = pi / SPP, sub = pi % SPP;
             const uint8_t* src;
-            if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
+            if (FOLD && sl >= 32) src = dbase + (size_t)(kDySigma + sl - 32) * 64 * (16 * SPP);
+            else if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
             else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP);
             else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
             // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
@@ -336,6 +355,13 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     // round trips per ring stage with both waves of a SIMD in lock-step), and the bias sums (16 VALU per k-step)
                     // sit behind the first MFMAs instead of in front of them.
                     constexpr int RD = NERFHIP_DW_RD, NM = 2 * NXT;
+                    [[maybe_unused]] bf16x8 as0, as1, bs0, bs1;
+                    if constexpr (FOLD) {                                 // dY_sigma (slabs 32, 33 of the stage) and X tile `wave`
+                        as0 = load_frag(st_base + 32 * SLAB_BYTES, 0);
+                        bs0 = load_frag(x_base + 2 * wave * SLAB_BYTES, 0);
+                        as1 = load_frag(st_base + 32 * SLAB_BYTES, 1);
+                        bs1 = load_frag(x_base + 2 * wave * SLAB_BYTES, 1);
+                    }
                     const bf16x8 a0 = load_frag(dy_base, 0);
                     bf16x8 b[RD];
 #pragma unroll
@@ -353,6 +379,20 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                         if (m == 1) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) dbacc += (float)a0[j];
+                        }
+                        if constexpr (FOLD) {
+                            if (m == 3) {
+                                acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as0, bs0, acc_sig, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) dbacc_sig += (float)as0[j];
+                            }
+                            if (m == NXT + 3) {
+                                acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as1, bs1, acc_sig, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) dbacc_sig += (float)as1[j];
+                            }
                         }
                         if (m == NXT + 1 || (NXT == 1 && m == 1)) {
 #pragma unroll
@@ -399,6 +439,13 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
             }
             sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
+            if constexpr (FOLD) {                // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
+                float* dst = sl + ((size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 64 + lane) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc_sig[4 * q], acc_sig[4 * q + 1], acc_sig[4 * q + 2], acc_sig[4 * q + 3]);
+                if (wave == 0) sl[((size_t)(0 * kDwMaxXTiles + kDwFoldBiasCol) * 64) * 16 + lane] = dbacc_sig;
+            }
         }
     };
     // job classes of mlp_layout.h kDwJobs: (X tiles, dY + X slabs per stage)
@@ -407,7 +454,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         case 2: run(integral_constant<int, 2>{}, integral_constant<int, 20>{}); break;                 // first layer: 16 + 4
         case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}); break;                 // rgb head: 2 + 8
         case 8:
-            if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
+            if (PREC == NERFHIP_BF16 && jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
+                run(integral_constant<int, 8>{}, integral_constant<int, (PREC == NERFHIP_BF16 ? 34 : 32)>{});   // final layer + folded sigma head: 16 + 16 + 2
+            else if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
             else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head: 2 + 16
             break;
         case 9: run(integral_constant<int, 9>{}, integral_constant<int, 26>{}); break;                 // dir layer: 8 + 18
@@ -696,7 +745,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
     const int jid = blockIdx.y;
     const DwJob jb = jobs.job[jid];
     const int model = jid / kNumDwJobs;
-    const int nsplit = jobs.nsplit[jid], s0 = jobs.soff[jid];
+    const int fold = jobs.fold_of[jid];                 // >= 0: this job's partials live in job `fold`'s slabs (row = X tile, column kDwFoldCol)
+    const int nsplit = jobs.nsplit[fold >= 0 ? fold : jid], s0 = jobs.soff[fold >= 0 ? fold : jid];
     const int n_ot = jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
     const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
     const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
@@ -716,7 +766,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
         if (m < 32) {
             float sacc = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) {
-                const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats + 8 * kDwMaxXTiles * 64 * 16 + ot * 64;
+                const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats +
+                                  (fold >= 0 ? (size_t)kDwFoldBiasCol * 64 * 16 : (size_t)8 * kDwMaxXTiles * 64 * 16 + ot * 64);
                 sacc += F8 ? sl[m] : sl[m] + sl[m + 32];
             }
             const int o = F8 ? 32 * ot + chain_feature(m >> 4, f8_row_h(m & 15), f8_row_j(m & 15)) : 32 * ot + m;
@@ -725,7 +776,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
     } else if (ot < n_ot && xt < n_xt) {
         const int e4 = threadIdx.x;                    // floats 4*e4 .. 4*e4+3 of the tile: lane = e4>>2, r = 4*(e4&3)+k
         const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
-                                                            ((size_t)(ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
+                                                            ((size_t)(fold >= 0 ? xt * kDwMaxXTiles + kDwFoldCol : ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) {
@@ -822,6 +873,9 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 #ifndef NERFHIP_DW_COST_B
 #define NERFHIP_DW_COST_B 35
 #endif
+#ifndef NERFHIP_DW_FOLD_SIGMA
+#define NERFHIP_DW_FOLD_SIGMA 1      // bf16: the final layer's workgroups also form the sigma head's gradient (same X: h8 read once)
+#endif
 #ifndef NERFHIP_DW_MIN_ITERS
 #define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
 #endif                               // takes ~4 to fill, and every split costs a 330 KB partial slab the reduce kernel re-reads
@@ -852,12 +906,18 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         // launch has not been re-measured.  NERFHIP_DW_COST_A / _B = a + b x KiB instead, for experiments)
         const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
         const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
-        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs);
+        const bool fold = dtype == NERFHIP_BF16 && NERFHIP_DW_FOLD_SIGMA;
+        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs + (fold && j % kNumDwJobs == kDwJobFinal ? 2 : 0));
         if (cost[j] < 1) cost[j] = 1;
         units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
         cap[j] = NERFHIP_DW_MIN_ITERS > 0 ? units[j] / NERFHIP_DW_MIN_ITERS : units[j];
         if (cap[j] > units[j]) cap[j] = units[j];
         if (cap[j] < 1) cap[j] = 1;
+        if (fold && j % kNumDwJobs == kDwJobSigma) {       // the final layer's workgroups form dW_sigma too: no workgroups of its own
+            cap[j] = 0;
+            ns[j] = 0;
+            continue;
+        }
         ns[j] = 1;
         ++total;
     }
@@ -886,6 +946,7 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
             jt->nsplit[j] = j < njobs ? ns[j] : 0;
             jt->soff[j] = off;
             jt->ntiles[j] = act_tiles(n_points[jj / kNumDwJobs], dtype);
+            jt->fold_of[j] = (j < njobs && ns[j] == 0 && j % kNumDwJobs == kDwJobSigma) ? j - kDwJobSigma + kDwJobFinal : -1;
             if (j < njobs) off += ns[j];
         }
         jt->soff[kDwMaxJobs] = off;
@@ -919,7 +980,10 @@ extern "C" int nerfhip_mlp_dw_plan(const int64_t* n_points_host, int n_models, i
     for (int j = 0; j < n_models * nerfhip::mlp::kNumDwJobs; ++j) {
         splits_out[j] = jt.nsplit[j];
         if (stage_kib_out) {
-            const int slabs = jt.job[j].dy_slabs + jt.job[j].x1_slabs + jt.job[j].x2_slabs;
+            int slabs = jt.job[j].dy_slabs + jt.job[j].x1_slabs + jt.job[j].x2_slabs;
+            if (jt.fold_of[j] >= 0) slabs = 0;                                        // folded into another job's stage
+            for (int k = 0; k < n_models * nerfhip::mlp::kNumDwJobs; ++k)
+                if (jt.fold_of[k] == j) slabs += jt.job[k].dy_slabs;
             stage_kib_out[j] = dtype == NERFHIP_F32 ? 2 * slabs : slabs;            // (the e4m3 kernel moves TWO tiles of slabs / 2 KiB each)
         }
     }
