@@ -122,9 +122,6 @@ static_assert(kDwJobs[kDwJobFinal].x1_off == kDwJobs[kDwJobSigma].x1_off && kDwJ
 constexpr int kDwFoldCol = 8;          // tile column of the final job's partial slab that holds the sigma partials (it uses columns 0..7)
 constexpr int kDwFoldBiasCol = 9;      // ... and the first 64 floats of (row 0, this column) its bias partial
 static_assert(kDwFoldBiasCol < kDwMaxXTiles, "fold columns inside the slab");
-#ifndef NERFHIP_DW_DEPTH
-#define NERFHIP_DW_DEPTH 4
-#endif
 #ifndef NERFHIP_DW_RING_KB
 #define NERFHIP_DW_RING_KB 160   // bf16 dW ring: the whole LDS of a CU, cut into as many stages as the JOB's stage size allows (round 4; the
                                  // depth itself measured neutral — 4 stages of 36 KiB run the same 480 us — the waves never wait for data)
@@ -153,10 +150,8 @@ static_assert(kDwFoldBiasCol < kDwMaxXTiles, "fold columns inside the slab");
 template <int PREC> struct DwTraits;
 template <> struct DwTraits<NERFHIP_BF16> {
     static constexpr int SPP = 1;            // 1 KiB pieces per slab
-    static constexpr int DEPTH = NERFHIP_DW_DEPTH;   // ring stages
-    static constexpr int MAXP = 36;          // max pieces per stage ((16 + 20) slabs)
-    static constexpr int STAGE_BYTES = MAXP * kPieceBytes;
-    static constexpr int RING_BYTES = NERFHIP_DW_RING_KB * 1024;
+    static constexpr int RING_BYTES = NERFHIP_DW_RING_KB * 1024;      // cut into stages of the job class's own size (dw_depth)
+    static constexpr int DEPTH = 0, STAGE_BYTES = 0;                  // (fp32 only: a fixed 2 x 72 KiB ring)
 };
 template <> struct DwTraits<NERFHIP_F32> {
     static constexpr int SPP = 2;
