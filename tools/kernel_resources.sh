@@ -30,5 +30,5 @@ for P in 1 0; do for M in 1 0; do for V in 0 1 2 3; do
   digest "fwd p$P m$M v$V" -DNH_PREC=$P -DNH_MODE=$M -DNH_VARIANT=$V $EXTRA nerf_pl_amd/csrc/mlp_fwd_variant.hip
 done; done; done
 digest mlp_bwd_chain -mllvm -amdgpu-sched-strategy=max-memory-clause nerf_pl_amd/csrc/mlp_bwd_chain.hip
-for f in mlp_bwd mlp_dx mlp_pack sampling composite posenc loss optim rays linear; do digest $f nerf_pl_amd/csrc/$f.hip; done
+for f in mlp_bwd mlp_dx mlp_pack prologue draws sampling composite posenc loss optim rays linear; do digest $f nerf_pl_amd/csrc/$f.hip; done
 rm -rf $TMP
