@@ -20,20 +20,17 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(DrawTable T, unsign
     }
     const int nf = mlp::padded_pieces(PREC), nb = mlp::bwd_padded_pieces(PREC);
     const int lane = threadIdx.x & 63;
-    const int piece = ((int)blockIdx.x - draw_blocks) * 4 + (int)(threadIdx.x >> 6);     // over (model, forward | W^T piece)
+    // one 1 KiB piece per wave, over (model, forward | W^T piece).  The piece index is wave-uniform and SAID to be so (readfirstlane):
+    // the model's tables are then read straight from the kernel arguments with scalar loads, as in mlp_pack_train_multi_kernel.
+    // (Round 4 first selected them into a local ParamTable; pack_*_piece index that table by layer, a dynamically indexed local
+    // lives in scratch memory — 200 B per lane, 59 MB of scratch stores per launch — and the launch took 29 us in the step's trace.)
+    const int piece = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - draw_blocks) * 4 + (int)(threadIdx.x >> 6));
     const int m = piece / (nf + nb), g = piece - m * (nf + nb);
     if (m >= n_models) return;
-    // (wave-uniform selects over the kernel arguments: no dynamically indexed copy of the table)
-    ParamTable pt = P.P[0];
-    uint8_t* packed = P.packed[0];
-    uint8_t* packed_bwd = P.packed_bwd[0];
-#pragma unroll
-    for (int k = 1; k < kPackMaxModels; ++k)
-        if (k == m) { pt = P.P[k]; packed = P.packed[k]; packed_bwd = P.packed_bwd[k]; }
     if (g < nf)
-        reinterpret_cast<uint4*>(packed + (size_t)g * mlp::kPieceBytes)[lane] = pack_fwd_piece<PREC>(pt, g, lane);
+        reinterpret_cast<uint4*>(P.packed[m] + (size_t)g * mlp::kPieceBytes)[lane] = pack_fwd_piece<PREC>(P.P[m], g, lane);
     else
-        reinterpret_cast<uint4*>(packed_bwd + (size_t)(g - nf) * mlp::kPieceBytes)[lane] = pack_bwd_piece<PREC>(pt, g - nf, lane);
+        reinterpret_cast<uint4*>(P.packed_bwd[m] + (size_t)(g - nf) * mlp::kPieceBytes)[lane] = pack_bwd_piece<PREC>(P.P[m], g - nf, lane);
 }
 
 }  // namespace nerfhip
