@@ -83,12 +83,22 @@ int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weig
                        const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K, float eps,
                        nerfhip_stream_t stream);
 
+/* Rounding of the pdf normaliser `torch.sum(weights, -1)` (rendering.py:30), on whose last bit the searchsorted indices of
+ * rendering.py:42 have knife edges (u == 1.0, cdf ties):
+ *   NERFHIP_ROW_TOTAL_EXACT  the correctly rounded fp32 sum (host-independent; what nerfhip_sample_pdf / nerfhip_fine_z use)
+ *   NERFHIP_ROW_TOTAL_ATEN   the fp32 additions in the order of ATen's CPU sum kernel (torch 2.x, every x86 capability:
+ *                            8-float vectors, 4 interleaved accumulators, scalar tail) = the reference's own bits on CPU;
+ *                            reproduces the (cdf, u) -> inds triples recorded at the reference's call site on every element */
+#define NERFHIP_ROW_TOTAL_EXACT 0
+#define NERFHIP_ROW_TOTAL_ATEN 1
+
 /* Same, additionally exporting what the fused kernel computed on the way (either may be NULL): cdf_out (B,M+1) = the
  * cdf of rendering.py:31-33 and inds_out (B,K) int64 = searchsorted(cdf, u, side='right') of rendering.py:42 — the
- * bit-exact contract of the path, checkable against the indices recorded at the reference's own call site.          */
+ * bit-exact contract of the path, checkable against the indices recorded at the reference's own call site.
+ * row_total: NERFHIP_ROW_TOTAL_*.                                                                                   */
 int nerfhip_sample_pdf_ex(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
                           const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K, float eps,
-                          float* cdf_out, int64_t* inds_out, nerfhip_stream_t stream);
+                          float* cdf_out, int64_t* inds_out, int row_total, nerfhip_stream_t stream);
 
 /* ---- a10. fine-pass depth assembly  (models/rendering.py:223-229) -----------------------
  * z_mid = midpoints(z_coarse); z_new = sample_pdf(z_mid, w_coarse[:,1:-1], N_i, u);
@@ -98,10 +108,10 @@ int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u,
                    float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
                    nerfhip_stream_t stream);
 
-/* Same with the optional exports of nerfhip_sample_pdf_ex: cdf_out (B,S_c-1), inds_out (B,N_i) int64.               */
+/* Same with the optional exports and the row_total choice of nerfhip_sample_pdf_ex: cdf_out (B,S_c-1), inds_out (B,N_i) int64. */
 int nerfhip_fine_z_ex(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride, float* z_fine,
                       float* z_new, int64_t B, int S_c, int N_i, float eps, float* cdf_out, int64_t* inds_out,
-                      nerfhip_stream_t stream);
+                      int row_total, nerfhip_stream_t stream);
 
 /* ---- a7. alpha compositing  (models/rendering.py:143-172) -------------------------------
  * raw: (B,S,4)=[r g b sigma] when raw_ch==4, or (B,S) sigma only when raw_ch==1 (weights_only).
@@ -126,12 +136,12 @@ int nerfhip_composite_train(const float* raw, const float* z, const float* rays,
                             float* opacity, float* g_raw, int64_t B, int S, nerfhip_stream_t stream);
 
 /* The coarse pass of a training step (rendering.py:143-172 + :223-229): nerfhip_composite_train and, for the same ray in the same
- * wave, nerfhip_fine_z on its weights (u / u_stride / N_i / eps / z_fine as there) — the weights travel from the quadrature to the
+ * wave, nerfhip_fine_z_ex on its weights (u / u_stride / N_i / eps / z_fine / row_total as there) — the weights travel from the quadrature to the
  * inverse-CDF sampling through LDS (`weights` may be NULL).  Bit-identical to the two launches.                            */
 int nerfhip_composite_train_fine_z(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
                                    int white_back, const float* target, float grad_scale, float* weights, float* rgb, float* depth,
                                    float* opacity, float* g_raw, int64_t B, int S, const float* u, int64_t u_stride, int N_i,
-                                   float eps, float* z_fine, nerfhip_stream_t stream);
+                                   float eps, float* z_fine, int row_total, nerfhip_stream_t stream);
 /* The last pass of a training step: nerfhip_composite_train + the loss values of nerfhip_mse_psnr (losses.py:9-14,
  * metrics.py:4-13) — out3 = [loss, psnr, mse] over this pass's rgb as the fine image and rgb_coarse (B,3; NULL when this pass is
  * the only one) as the coarse image, reduced by the last workgroup to finish in nerfhip_mse_psnr's own order (same bits).

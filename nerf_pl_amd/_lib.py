@@ -33,9 +33,9 @@ SIGNATURES = {
     "nerfhip_sample_pdf": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _int, _int, _f32,
                            _c_void_p],
     "nerfhip_sample_pdf_ex": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _int, _int, _f32,
-                              _c_void_p, _c_void_p, _c_void_p],
+                              _c_void_p, _c_void_p, _int, _c_void_p],
     "nerfhip_fine_z_ex": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _int, _int, _f32,
-                          _c_void_p, _c_void_p, _c_void_p],
+                          _c_void_p, _c_void_p, _int, _c_void_p],
     "nerfhip_fine_z": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _int, _int, _f32,
                        _c_void_p],
     "nerfhip_composite_fwd": [_c_void_p, _int, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _c_void_p,
@@ -73,7 +73,7 @@ SIGNATURES = {
     "nerfhip_composite_train": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
                                 _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
     "nerfhip_composite_train_fine_z": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
-                                       _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p, _i64, _int, _f32, _c_void_p, _c_void_p],
+                                       _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p, _i64, _int, _f32, _c_void_p, _int, _c_void_p],
     "nerfhip_composite_train_loss": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
                                      _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "nerfhip_mlp_fwd_rays_coarse": [_c_void_p, _c_void_p, _c_void_p, _i64, _int, _int, _f32, _c_void_p, _c_void_p, _int, _int,

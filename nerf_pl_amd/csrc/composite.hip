@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void composite_train_fine_z_kernel(const float
                                                                      float* __restrict__ depth, float* __restrict__ opacity,
                                                                      float* __restrict__ g_raw, int64_t B, int S,
                                                                      const float* __restrict__ u, int64_t u_stride, int N, float eps,
-                                                                     float* __restrict__ z_fine) {
+                                                                     float* __restrict__ z_fine, int row_total) {
     // Two rays per workgroup, two waves per ray — both chains are latency-bound and independent once the weights exist, so they
     // run side by side: waves 0-1 composite (quadrature, loss gradient, backward sweep), waves 2-3 form the same rays' weights
     // again (forward sweep only, raw is in L2) and assemble the fine depths from them.
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void composite_train_fine_z_kernel(const float
         composite_weights_wave(raw, z, rays, noise, noise_std, r, S, w_s, lane);
         __builtin_amdgcn_wave_barrier();
         fine_z_wave(w_s + S4, z + r * S, [&](int j) { return w_s[1 + j]; }, u ? u + r * u_stride : nullptr, S, N, eps,
-                    z_fine + r * (S + N), nullptr, nullptr, nullptr, lane);
+                    z_fine + r * (S + N), nullptr, nullptr, nullptr, lane, row_total);
     }
 }
 
@@ -487,8 +487,9 @@ extern "C" int nerfhip_composite_bwd(const float* raw, int raw_ch, const float* 
 extern "C" int nerfhip_composite_train_fine_z(const float* raw, const float* z, const float* rays, const float* noise, float noise_std,
                                               int white_back, const float* target, float grad_scale, float* weights, float* rgb,
                                               float* depth, float* opacity, float* g_raw, int64_t B, int S, const float* u,
-                                              int64_t u_stride, int N_i, float eps, float* z_fine, nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(B >= 0 && S >= 3 && S <= 2048 && N_i >= 1);
+                                              int64_t u_stride, int N_i, float eps, float* z_fine, int row_total,
+                                              nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S >= 3 && S <= 2048 && N_i >= 1 && (row_total == 0 || row_total == 1));
     const int S4 = (S + 3) & ~3, N4 = (N_i + 3) & ~3;
     const size_t per_wave = (size_t)(2 * S4 + 3 * S4 + N4 + ((S + 1 + 3) & ~3) + N4) * sizeof(float);
     NERFHIP_CHECK_ARG(2 * per_wave <= 65536);
@@ -498,7 +499,7 @@ extern "C" int nerfhip_composite_train_fine_z(const float* raw, const float* z, 
     if (noise_std == 0.0f) noise = nullptr;
     hipLaunchKernelGGL(nerfhip::composite_train_fine_z_kernel, dim3((unsigned)((B + 1) / 2)), dim3(256), 2 * per_wave,
                        (hipStream_t)stream, raw, z, rays, noise, noise_std, white_back, target, grad_scale, weights, rgb, depth,
-                       opacity, g_raw, B, S, u, u_stride, N_i, eps, z_fine);
+                       opacity, g_raw, B, S, u, u_stride, N_i, eps, z_fine, row_total);
     return nerfhip_launch_status();
 }
 

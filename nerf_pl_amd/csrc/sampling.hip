@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
                                                           const float* __restrict__ u, int64_t u_stride,
                                                           float* __restrict__ samples, int64_t B, int M, int K,
                                                           float eps, float* __restrict__ cdf_out,
-                                                          int64_t* __restrict__ inds_out) {
+                                                          int64_t* __restrict__ inds_out, int row_total) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     float* bins_s = cdf_s + (M + 1);
     for (int j = lane; j <= M; j += 64) bins_s[j] = bins[r * bins_stride + j];
     const float* wrow = weights + r * w_stride;
-    build_cdf_wave([&](int j) { return wrow[j]; }, M, eps, cdf_s, lane);
+    build_cdf_wave([&](int j) { return wrow[j]; }, M, eps, cdf_s, lane, row_total);
     if (cdf_out)
         for (int j = lane; j <= M; j += 64) cdf_out[r * (M + 1) + j] = cdf_s[j];
     for (int k = lane; k < K; k += 64) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
                                                       const float* __restrict__ u, int64_t u_stride,
                                                       float* __restrict__ zf, float* __restrict__ znew_out,
                                                       int64_t B, int S, int N, float eps, float* __restrict__ cdf_out,
-                                                      int64_t* __restrict__ inds_out) {
+                                                      int64_t* __restrict__ inds_out, int row_total) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void fine_z_kernel(const float* __restrict__ z
     const float* wrow = wc + r * S + 1;         // weights_coarse[:, 1:-1]          :225
     fine_z_wave(lds + (size_t)wave * fine_z_lds_floats(S, N), zc + r * S, [&](int j) { return wrow[j]; },
                 u ? u + r * u_stride : nullptr, S, N, eps, zf + r * (S + N), znew_out ? znew_out + r * N : nullptr,
-                cdf_out ? cdf_out + r * (S - 1) : nullptr, inds_out ? inds_out + r * N : nullptr, lane);
+                cdf_out ? cdf_out + r * (S - 1) : nullptr, inds_out ? inds_out + r * N : nullptr, lane, row_total);
 }
 
 }  // namespace nerfhip
@@ -120,37 +120,37 @@ extern "C" int nerfhip_searchsorted_left(const float* a, const float* v, int64_t
 
 extern "C" int nerfhip_sample_pdf_ex(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
                                      const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K,
-                                     float eps, float* cdf_out, int64_t* inds_out, nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(B >= 0 && M >= 1 && K >= 0 && M <= 2040);
+                                     float eps, float* cdf_out, int64_t* inds_out, int row_total, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && M >= 1 && K >= 0 && M <= 2040 && (row_total == 0 || row_total == 1));
     if (B == 0 || K == 0) return 0;
     NERFHIP_CHECK_ARG(bins && weights && samples);
     hipLaunchKernelGGL(nerfhip::sample_pdf_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256),
                        (size_t)4 * 2 * (M + 1) * sizeof(float), (hipStream_t)stream, bins, bins_stride, weights,
-                       w_stride, u, u_stride, samples, B, M, K, eps, cdf_out, inds_out);
+                       w_stride, u, u_stride, samples, B, M, K, eps, cdf_out, inds_out, row_total);
     return nerfhip_launch_status();
 }
 extern "C" int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weights, int64_t w_stride,
                                   const float* u, int64_t u_stride, float* samples, int64_t B, int M, int K,
                                   float eps, nerfhip_stream_t stream) {
     return nerfhip_sample_pdf_ex(bins, bins_stride, weights, w_stride, u, u_stride, samples, B, M, K, eps, nullptr, nullptr,
-                                 stream);
+                                 NERFHIP_ROW_TOTAL_EXACT, stream);
 }
 
 extern "C" int nerfhip_fine_z_ex(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
                                  float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps, float* cdf_out,
-                                 int64_t* inds_out, nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(B >= 0 && S_c >= 3 && N_i >= 1);
+                                 int64_t* inds_out, int row_total, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(B >= 0 && S_c >= 3 && N_i >= 1 && (row_total == 0 || row_total == 1));
     const int S4 = (S_c + 3) & ~3, N4 = (N_i + 3) & ~3;
     const size_t per_wave = (size_t)(3 * S4 + N4 + ((S_c + 1 + 3) & ~3) + N4) * sizeof(float);
     NERFHIP_CHECK_ARG(4 * per_wave <= 65536);
     if (B == 0) return 0;
     NERFHIP_CHECK_ARG(z_coarse && w_coarse && z_fine);
     hipLaunchKernelGGL(nerfhip::fine_z_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 4 * per_wave,
-                       (hipStream_t)stream, z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, cdf_out, inds_out);
+                       (hipStream_t)stream, z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, cdf_out, inds_out, row_total);
     return nerfhip_launch_status();
 }
 extern "C" int nerfhip_fine_z(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_stride,
                               float* z_fine, float* z_new, int64_t B, int S_c, int N_i, float eps,
                               nerfhip_stream_t stream) {
-    return nerfhip_fine_z_ex(z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, nullptr, nullptr, stream);
+    return nerfhip_fine_z_ex(z_coarse, w_coarse, u, u_stride, z_fine, z_new, B, S_c, N_i, eps, nullptr, nullptr, NERFHIP_ROW_TOTAL_EXACT, stream);
 }

@@ -28,13 +28,87 @@ __device__ __forceinline__ int upper_bound(P a, int n, float v) {
 }
 
 // ---- shared per-wave inverse-CDF machinery ---------------------------------------------------
+// Row total of the pdf normaliser (rendering.py:30, `torch.sum(weights, -1, keepdim=True)` on fp32), two selectable roundings:
+//   ROW_TOTAL_EXACT  the fp64 sum of the fp32 terms rounded once — the correctly rounded total (exact here: the terms span < 29
+//                    binades), independent of any host; the default
+//   ROW_TOTAL_ATEN   the value ATen's CPU kernel returns, bit for bit: its fp32 additions in its own order (SumKernel.cpp
+//                    cascade_sum -> vectorized_inner_sum -> row_sum: 8-float vectors — on every x86 capability of torch 2.x,
+//                    AVX-512 builds included — four interleaved vector accumulators ("ILP") with a 16-step cascade, the
+//                    leftover vectors into accumulator 0, accumulators 1-3 added to 0, then a scalar chain: 0 + the row's
+//                    tail elements + the 8 vector lanes in order; rows shorter than 8 take the same path with 1-float
+//                    "vectors").  The reference's searchsorted indices have knife edges on the last bit of this total
+//                    (u == 1.0, cdf ties), so THIS is the mode that reproduces the (cdf, u) -> inds triples recorded at
+//                    rendering.py:42 on 100 % of the elements (tests/test_gpu_parity.py); oracle/nerf_oracle.py
+//                    aten_row_total is the same restatement in numpy, pinned against torch.sum itself.
+constexpr int ROW_TOTAL_EXACT = 0, ROW_TOTAL_ATEN = 1;
+
+// ATen multi_row_sum for ONE vector lane: `n` steps over four interleaved accumulators, step i adding term(4 i + k) to k
+template <typename Term>
+__device__ __forceinline__ void aten_ilp_cascade(Term term, int n, float (&ps)[4]) {
+    int cl2 = 0;
+    while ((1 << cl2) < n) ++cl2;                                   // utils::CeilLog2(n)
+    const int level_power = (cl2 / 4 > 4) ? cl2 / 4 : 4;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[j][k] = 0.0f;
+    int i = 0;
+    while (i + level_step <= n) {
+        for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[0][k] = nh_add(acc[0][k], term(4 * i + k));
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[j][k] = nh_add(acc[j][k], acc[j - 1][k]); acc[j - 1][k] = 0.0f; }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < n; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] = nh_add(acc[0][k], term(4 * i + k));
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] = nh_add(acc[0][k], acc[j][k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ps[k] = acc[0][k];
+}
+
+// term(j), j in [0, M): the row's fp32 terms; every lane returns the total
+template <typename Term>
+__device__ __forceinline__ float aten_row_total_wave(Term term, int M, int lane) {
+    const int V = (M >= 8) ? 8 : 1;                 // Vectorized<float> of the sum kernel; scalar path below one vector
+    const int vs = M / V, n_ilp = vs / 4;
+    float part = 0.0f;                              // lane l < V: vector lane l of row_sum's result
+    if (lane < V) {
+        auto vterm = [&](int i) { return term(i * V + lane); };
+        float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (n_ilp > 0) aten_ilp_cascade(vterm, n_ilp, ps);
+        for (int i = n_ilp * 4; i < vs; ++i) ps[0] = nh_add(ps[0], vterm(i));
+        part = nh_add(nh_add(nh_add(ps[0], ps[1]), ps[2]), ps[3]);
+    }
+    float acc = 0.0f;
+    if (V > 1)
+        for (int k = vs * V; k < M; ++k) acc = nh_add(acc, term(k));            // the row's tail, scalar
+    for (int k = 0; k < V; ++k) acc = nh_add(acc, __shfl(part, k, 64));         // then the vector lanes in order
+    return acc;
+}
+
 // cdf_s: M+1 floats in LDS (built here), bins_s: M+1 floats in LDS (filled by the caller).
 template <typename WLoad>
-__device__ __forceinline__ void build_cdf_wave(WLoad wload, int M, float eps, float* cdf_s, int lane) {
-    // weights + eps, total (fp64 sum of the fp32 terms, rounded once)            rendering.py:29-30
-    double part = 0.0;
-    for (int j = lane; j < M; j += 64) part += (double)nh_add(wload(j), eps);
-    const float total = (float)wave_sum(part);
+__device__ __forceinline__ void build_cdf_wave(WLoad wload, int M, float eps, float* cdf_s, int lane, int row_total = ROW_TOTAL_EXACT) {
+    // weights + eps, total                                                        rendering.py:29-30
+    float total;
+    if (row_total == ROW_TOTAL_ATEN) {              // (wave-uniform)
+        total = aten_row_total_wave([&](int j) { return nh_add(wload(j), eps); }, M, lane);
+    } else {
+        double part = 0.0;
+        for (int j = lane; j < M; j += 64) part += (double)nh_add(wload(j), eps);
+        total = (float)wave_sum(part);
+    }
     // cdf = [0, cumsum(pdf)]                                                      :31-33
     double carry = 0.0;
     for (int j0 = 0; j0 < M; j0 += 64) {
@@ -77,7 +151,8 @@ __device__ __forceinline__ int fine_z_lds_floats(int S, int N) {
 template <typename WLoad>
 __device__ __forceinline__ void fine_z_wave(float* lds, const float* __restrict__ zrow, WLoad wload, const float* __restrict__ urow,
                                             int S, int N, float eps, float* __restrict__ out, float* __restrict__ znew,
-                                            float* __restrict__ cdf_row, int64_t* __restrict__ inds_row, int lane) {
+                                            float* __restrict__ cdf_row, int64_t* __restrict__ inds_row, int lane,
+                                            int row_total = ROW_TOTAL_EXACT) {
     const int M = S - 2;                        // number of pdf bins
     const int S4 = (S + 3) & ~3, N4 = (N + 3) & ~3, H4 = (S + 1 + 3) & ~3;
     float* zc_s = lds;
@@ -91,7 +166,7 @@ __device__ __forceinline__ void fine_z_wave(float* lds, const float* __restrict_
     if (lane < N4 - N) zn_s[N + lane] = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < S - 1; j += 64) bins_s[j] = nh_mul(0.5f, nh_add(zc_s[j], zc_s[j + 1]));  // :223
-    build_cdf_wave(wload, M, eps, cdf_s, lane);
+    build_cdf_wave(wload, M, eps, cdf_s, lane, row_total);
     if (cdf_row)
         for (int j = lane; j <= M; j += 64) cdf_row[j] = cdf_s[j];
     for (int k = lane; k < N; k += 64) {

@@ -5,6 +5,14 @@ through the DataLoader (train.py:89-94); on the GPU that is five ~5 us launches 
 bit for bit what those torch calls return for the generator's current (seed, offset) — from one HIP launch and advances the
 generator by what the calls would have consumed, so a run is the same run whichever path draws (`tests/test_gpu_draws.py`).
 
+Self-check.  The launch REPLICATES ATen's Philox consumption (offset arithmetic, Box-Muller, the 32- / 64-bit randint paths) —
+pinned by the GPU tests on torch 2.10 + ROCm 7.0, but a torch upgrade could move it silently.  The first use on a device
+therefore draws the same short uniform / normal / integer sequences through torch and through the replica from two private
+generators at the same (seed, offset) and compares values and offsets bit for bit (`replica_ok`); on a mismatch this module
+warns once and makes every draw with torch's own calls from then on (same values as an all-torch run, the reference's launch
+count: the batch's rays and the weight images then come from their stand-alone launches).  NERFHIP_DRAWS=torch forces that path,
+NERFHIP_DRAWS=replica skips the check.
+
 hipGraph capture.  A captured launch cannot take (seed, offset) by value: every replay must walk on.  While the current stream
 is capturing, `draws()` reads them from a device-resident `GraphDrawState` that the kernel itself advances (last workgroup,
 arrival ticket); the owner of the graph (`system.GraphedTrainStep`) arms its state before the capture, captures under
@@ -12,6 +20,8 @@ arrival ticket); the owner of the graph (`system.GraphedTrainStep`) arms its sta
 replays stay on the same stream.
 """
 import ctypes
+import os
+import warnings
 
 import torch
 
@@ -21,6 +31,10 @@ from ._lib import DRAW_NORMAL, DRAW_RANDINT, DRAW_UNIFORM, check, ptr, stream_pt
 _KINDS = {"rand": DRAW_UNIFORM, "randn": DRAW_NORMAL, "randint": DRAW_RANDINT}
 _MAX_BLOCKS = {}
 _GRAPH_STATES = {}
+_REPLICA = {}          # device index -> True: the replica reproduces this torch build's streams | False: torch's own draws
+# the self-check's draws: shapes that take the single- and the multi-block path, both randint widths (high < / >= 2^28)
+_CHECK_SPECS = (("randint", (1000,), 64000000), ("rand", (257, 64)), ("randn", (257, 192)), ("randint", (129,), 1 << 40),
+                ("rand", (3,)), ("randn", (5, 7)))
 
 
 def max_blocks(device):
@@ -43,6 +57,56 @@ def _generator(device, generator):
     return torch.cuda.default_generators[idx]
 
 
+def _index(device):
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def _torch_draw(spec, device, generator):
+    kind, shape = spec[0], tuple(int(x) for x in spec[1])
+    if kind == "randint":
+        return torch.randint(0, int(spec[2]), shape, device=device, generator=generator)
+    return (torch.rand if kind == "rand" else torch.randn)(*shape, device=device, generator=generator)
+
+
+def _self_check(device):
+    """torch's own rand / randn / randint against the replica, from two private generators at the same (seed, offset)."""
+    device = torch.device("cuda", _index(device))
+    seed, off = 0x5eed5eed, 4 * 977
+    g_t, g_r = torch.Generator(device=device), torch.Generator(device=device)
+    for g in (g_t, g_r):
+        g.manual_seed(seed)
+        g.set_offset(off)
+    want = [_torch_draw(sp, device, g_t) for sp in _CHECK_SPECS]
+    got = _replica_draws(list(_CHECK_SPECS), device, g_r, None, None)
+    same = all(torch.equal(a, b) for a, b in zip(want, got))
+    return bool(same) and int(g_t.get_offset()) == int(g_r.get_offset())
+
+
+def replica_ok(device):
+    """Does the Philox replica reproduce THIS torch build's generator streams on `device`?  Checked once per device, outside
+    any capture (GraphDrawState.arm() asks before a capture starts)."""
+    idx = _index(device)
+    ok = _REPLICA.get(idx)
+    if ok is None:
+        mode = os.environ.get("NERFHIP_DRAWS", "check")
+        if mode == "torch":
+            ok = False
+        elif mode == "replica":
+            ok = True
+        else:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.NerfHipError("draws: first use on this device inside a hipGraph capture — call draws.replica_ok(device) "
+                                        "(or GraphDrawState.arm()) before capturing")
+            ok = _self_check(device)
+            if not ok:
+                warnings.warn("nerf_pl_amd.draws: the Philox replica does not reproduce torch %s's rand / randn / randint stream "
+                              "on this device; falling back to torch's own draws (separate launches, same values as an "
+                              "all-torch run)" % torch.__version__)
+        _REPLICA[idx] = ok
+    return ok
+
+
 class GraphDrawState:
     """(seed, offset) of one generator in device memory, for captured launches: {seed, offset, arrival ticket, -} as 4 x int64."""
 
@@ -60,6 +124,7 @@ class GraphDrawState:
         self.seed, self.expect = int(g.initial_seed()), int(g.get_offset())
         self.increment = 0
         self._upload()
+        replica_ok(self.device)            # (the self-check cannot run once the capture has begun)
 
     def _upload(self):
         wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v          # uint64 bit patterns in an int64 tensor
@@ -125,6 +190,37 @@ def draws(specs, device, generator=None, batch=None, pack=None):
     n = len(specs)
     if not 1 <= n <= 6:
         raise ValueError("draws: 1..6 draws per launch")
+    if not replica_ok(device):
+        return _torch_draws(specs, device, generator, batch, pack)
+    return _replica_draws(specs, device, generator, batch, pack)
+
+
+def _torch_draws(specs, device, generator, batch, pack):
+    """The same tensors from torch's own calls, in order (unread draws are made and dropped: the stream must advance as the
+    reference's does); the batch's rays / colours and the weight images from their stand-alone launches."""
+    from . import ops
+    outs = []
+    with torch.cuda.device(device):
+        for sp in specs:
+            kind = _KINDS[sp[0]]
+            live = not (len(sp) > (3 if kind == DRAW_RANDINT else 2) and sp[-1] is False)
+            t = _torch_draw(sp, device, generator)
+            outs.append(t if live or (batch is not None and not outs) else None)
+        if batch is not None:
+            ids = outs[0].reshape(-1).contiguous()
+            check(_lib.load().nerfhip_sample_batch(batch.c2w, ptr(ids), batch.rgbs_all, ids.numel(), batch.H, batch.W, batch.focal,
+                                                   batch.near, batch.far, batch.use_ndc, batch.ndc_near_plane, batch.rays, batch.rgbs,
+                                                   stream_ptr()), "nerfhip_sample_batch")
+            sp = specs[0]
+            if len(sp) > 3 and sp[-1] is False:
+                outs[0] = None
+    if pack is not None:
+        ops.pack_models_train(*pack)
+    return outs
+
+
+def _replica_draws(specs, device, generator, batch, pack):
+    n = len(specs)
     outs, arr = [], (_lib.Draw * n)()
     with torch.cuda.device(device):
         for i, sp in enumerate(specs):
@@ -173,6 +269,27 @@ def draws(specs, device, generator=None, batch=None, pack=None):
         if pack is not None:
             ops.mark_packed(pack[0])
     return outs
+
+
+def in_graph_stream(device):
+    """True while the current stream is capturing under an armed GraphDrawState for `device`: draws made now must come from
+    draws() — the device-resident stream the captured batch / step draws walk — and not from torch's own capture-time generator
+    bookkeeping, which starts every replay at the same offset as that state (the two would hand out the same Philox counters)."""
+    return torch.cuda.is_current_stream_capturing() and _capture_state(torch.device(device)) is not None and replica_ok(device)
+
+
+def rand(shape, device):
+    """torch.rand(*shape, device=device) on the default generator's stream — through draws() inside a capture that owns a
+    GraphDrawState (same values either way)."""
+    if in_graph_stream(device):
+        return draws([("rand", shape)], device)[0]
+    return torch.rand(*shape, device=device)
+
+
+def randn(shape, device):
+    if in_graph_stream(device):
+        return draws([("randn", shape)], device)[0]
+    return torch.randn(*shape, device=device)
 
 
 def step_specs(B, S, N, perturb, noise_std):

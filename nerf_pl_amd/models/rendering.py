@@ -12,6 +12,7 @@ kernel) -> NeRF.forward layer by layer (csrc/linear.hip), in point chunks of `ch
 """
 import torch
 
+from .. import draws as D
 from .. import ops
 from .mlp_autograd import mlp_rays
 
@@ -92,10 +93,19 @@ def render_rays(models,
         def mlp(model, z, sigma_only):
             return _mlp_points(model, embeddings[0], rays, z, dir_embedded, sigma_only, int(chunk))
 
-    # RNG: identical calls, order, shapes and device as the reference
-    perturb_rand = torch.rand(N_rays, N_samples, device=dev) if perturb > 0 else None      # :203
+    # RNG: identical calls, order, shapes and device as the reference.  Inside a hipGraph capture that owns a
+    # device-resident generator state (system.GraphedTrainStep: its batch source draws through draws.py) these four come from the
+    # same state — torch's own capture-time bookkeeping would restart every replay at the offset that state starts from.
+    graph_rng = dev.type == "cuda" and D.in_graph_stream(dev)
+
+    def rand(*shape):
+        return D.rand(shape, dev) if graph_rng else torch.rand(*shape, device=dev)
+
+    def randn(*shape):
+        return D.randn(shape, dev) if graph_rng else torch.randn(*shape, device=dev)
+    perturb_rand = rand(N_rays, N_samples) if perturb > 0 else None                        # :203
     z_vals = ops.sample_coarse_z(rays, N_samples, use_disp, perturb, perturb_rand)          # :189-204
-    noise_c = torch.randn(N_rays, N_samples, device=dev)                                    # :152 (always drawn)
+    noise_c = randn(N_rays, N_samples)                                                      # :152 (always drawn)
 
     raw_c = mlp(model_coarse, z_vals, bool(test_time))                                      # :206-217
     if test_time:
@@ -106,9 +116,9 @@ def render_rays(models,
         result = {'rgb_coarse': rgb_c, 'depth_coarse': depth_c, 'opacity_coarse': opacity_c}
 
     if N_importance > 0:                                                                    # :222-242
-        u = torch.rand(N_rays, N_importance, device=dev) if perturb != 0 else None          # :39, det=(perturb==0)
+        u = rand(N_rays, N_importance) if perturb != 0 else None                            # :39, det=(perturb==0)
         z_fine = ops.fine_z(z_vals, weights_coarse.detach(), N_importance, u=u)             # :223-229 (.detach :226)
-        noise_f = torch.randn(N_rays, N_samples + N_importance, device=dev)                 # :152
+        noise_f = randn(N_rays, N_samples + N_importance)                                   # :152
         raw_f = mlp(models[1], z_fine, False)
         _, opacity_f, rgb_f, depth_f = ops.composite(raw_f, z_fine, rays, noise_f, noise_std, white_back)
         result['rgb_fine'] = rgb_f

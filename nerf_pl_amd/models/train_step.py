@@ -56,8 +56,11 @@ class _TrainRender(torch.autograd.Function):
             raise ValueError("render_rays_train: noise_std != 0 needs the noise draws")
         # weight images: the batch's launch packed them (RayStore.sample(pack_models=...)) and the weights have not moved since —
         # else ONE pack launch for both models here
+        # (only models whose optimizer ANNOUNCES its updates — FlatAdam bumps `_weights_serial` and marks `_serial_tracked` — can
+        # vouch for a pack made before this call; under any other optimizer the serials never move and the images are re-packed)
         fresh = (packed is not None and packed[0] == tuple(id(m) for m in models) and packed[1] == dtype
-                 and all(getattr(m, "_weights_serial", 0) == sr and getattr(m, "_packed_serial", None) == sr for m, sr in zip(models, packed[2])))
+                 and all(getattr(m, "_serial_tracked", False) and getattr(m, "_weights_serial", 0) == sr
+                         and getattr(m, "_packed_serial", None) == sr for m, sr in zip(models, packed[2])))
         packs = [m.train_buffers(dtype, dev) for m in models] if fresh else ops.pack_models_train(models, dtype)
         # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`
         gscale = float(np.float32(2.0) / np.float32(3 * B))

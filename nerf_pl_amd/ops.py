@@ -5,6 +5,7 @@ the current HIP stream through ctypes, and raises `NerfHipError` on any non-zero
 no CPU path and no eager-PyTorch fallback: tensors must live on an MI355X.
 """
 import ctypes
+import os
 
 import torch
 
@@ -85,13 +86,15 @@ def sample_coarse_z(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=N
 @device_guard
 def searchsorted(a, v, out=None, side="left"):
     """Drop-in for torchsearchsorted.searchsorted (reference models/rendering.py:2,42): batched
-    row-wise numpy-style searchsorted; a (B,M), v (B,K) float32 -> int64 (B,K)."""
+    row-wise numpy-style searchsorted; a (B,M), v (B,K) float32 -> int64 (B,K).  Like the extension, `a` or `v` may have ONE
+    row, which then serves every row of the other (the reference itself never uses that form: rendering.py:42)."""
     require_gpu(a, v)
     if side not in ("left", "right"):
         raise ValueError("side must be 'left' or 'right'")
-    a, v = _c(a), _c(v)
-    if a.dim() != 2 or v.dim() != 2 or a.shape[0] != v.shape[0]:
-        raise ValueError("searchsorted expects a (B,M) and v (B,K)")
+    if a.dim() != 2 or v.dim() != 2 or not (a.shape[0] == v.shape[0] or a.shape[0] == 1 or v.shape[0] == 1):
+        raise ValueError("searchsorted expects a (B,M) and v (B,K), or one of them with a single row")
+    rows = max(a.shape[0], v.shape[0])
+    a, v = _c(a.expand(rows, a.shape[1])), _c(v.expand(rows, v.shape[1]))
     B, M = a.shape
     K = v.shape[1]
     if out is None:
@@ -101,6 +104,22 @@ def searchsorted(a, v, out=None, side="left"):
     fn = _lib.load().nerfhip_searchsorted_right if side == "right" else _lib.load().nerfhip_searchsorted_left
     check(fn(ptr(a), ptr(v), ptr(out), B, M, K, stream_ptr()), "nerfhip_searchsorted_" + side)
     return out
+
+
+# Rounding of sample_pdf's normaliser `torch.sum(weights, -1)` (rendering.py:30; include/nerfhip.h NERFHIP_ROW_TOTAL_*): "exact" =
+# the correctly rounded fp32 sum (host-independent, the default), "aten" = the reference's own bits on a CPU (ATen's fp32
+# addition order), under which the searchsorted indices recorded at the reference's call site are reproduced on every element.
+# Process-wide (every sample_pdf / fine_z / fused training launch reads it at call time); NERFHIP_ROW_TOTAL=aten in the environment.
+_ROW_TOTAL_MODES = {"exact": 0, "aten": 1}
+_row_total = _ROW_TOTAL_MODES[os.environ.get("NERFHIP_ROW_TOTAL", "exact")]
+
+
+def set_row_total(mode):
+    """Select the rounding of sample_pdf's row total: "exact" | "aten".  Returns the previous mode's name."""
+    global _row_total
+    prev = [k for k, v in _ROW_TOTAL_MODES.items() if v == _row_total][0]
+    _row_total = _ROW_TOTAL_MODES[mode]
+    return prev
 
 
 @device_guard
@@ -128,7 +147,8 @@ def sample_pdf_u(bins, weights, n_importance, u=None, eps=1e-5, return_cdf_inds=
     cdf = torch.empty(B, M + 1, device=bins.device, dtype=torch.float32) if return_cdf_inds else None
     inds = torch.empty(B, n_importance, device=bins.device, dtype=torch.int64) if return_cdf_inds else None
     check(_lib.load().nerfhip_sample_pdf_ex(ptr(bins), bins.stride(0), ptr(weights), weights.stride(0), ptr(u), u_stride,
-                                            ptr(samples), B, M, n_importance, float(eps), ptr(cdf), ptr(inds), stream_ptr()),
+                                            ptr(samples), B, M, n_importance, float(eps), ptr(cdf), ptr(inds), _row_total,
+                                            stream_ptr()),
           "nerfhip_sample_pdf")
     return (samples, cdf, inds) if return_cdf_inds else samples
 
@@ -149,7 +169,7 @@ def fine_z(z_coarse, w_coarse, n_importance, u=None, eps=1e-5, return_new=False,
     cdf = torch.empty(B, S - 1, device=z_coarse.device, dtype=torch.float32) if return_cdf_inds else None
     inds = torch.empty(B, n_importance, device=z_coarse.device, dtype=torch.int64) if return_cdf_inds else None
     check(_lib.load().nerfhip_fine_z_ex(ptr(z_coarse), ptr(w_coarse), ptr(u), u_stride, ptr(zf), ptr(zn), B, S,
-                                        n_importance, float(eps), ptr(cdf), ptr(inds), stream_ptr()), "nerfhip_fine_z")
+                                        n_importance, float(eps), ptr(cdf), ptr(inds), _row_total, stream_ptr()), "nerfhip_fine_z")
     out = (zf, zn) if return_new else (zf,)
     if return_cdf_inds:
         out = out + (cdf, inds)
@@ -246,10 +266,12 @@ def composite_train_fine_z(raw, z, rays, noise, noise_std, white_back, target, g
     if raw.numel() != B * S * 4 or target.numel() != B * 3:
         raise ValueError("composite_train_fine_z: raw must be (B,S,4) and target (B,3)")
     noise = None if noise_std == 0 else (_c(noise) if noise is not None else None)
+    _check_draw("composite_train_fine_z", "noise", noise, B * S)
     u_stride = 0
     if u is not None:
         u = _c(u)
         u_stride = n_importance if u.dim() == 2 else 0
+        _check_draw("composite_train_fine_z", "u", u, B * n_importance if u.dim() == 2 else n_importance)
     dev = z.device
     weights = torch.empty(B, S, device=dev, dtype=torch.float32) if want_weights else None
     opacity = torch.empty(B, device=dev, dtype=torch.float32)
@@ -260,16 +282,24 @@ def composite_train_fine_z(raw, z, rays, noise, noise_std, white_back, target, g
     check(_lib.load().nerfhip_composite_train_fine_z(ptr(raw), ptr(z), ptr(rays), ptr(noise), float(noise_std), int(bool(white_back)),
                                                      ptr(target), float(grad_scale), ptr(weights), ptr(rgb), ptr(depth), ptr(opacity),
                                                      ptr(g_raw), B, S, ptr(u), u_stride, int(n_importance), float(eps), ptr(zf),
-                                                     stream_ptr()), "nerfhip_composite_train_fine_z")
+                                                     _row_total, stream_ptr()), "nerfhip_composite_train_fine_z")
     return weights, opacity, rgb, depth, g_raw, zf
 
 
 _TICKETS = {}
 
 
+def _check_draw(op, name, t, numel):
+    """caller-supplied draw tensors (batch['draws'] may have been made for other hyper-parameters): a wrong size would be an
+    out-of-bounds device read, not an error"""
+    if t is not None and (t.numel() != numel or t.dtype != torch.float32):
+        raise ValueError("%s: %s must hold %d fp32 draws, got %s %s" % (op, name, numel, tuple(t.shape), t.dtype))
+
+
 def _ticket(device):
-    """one zero-initialised device word per GPU for the arrival-ticket kernels (they leave it at zero)"""
-    key = device.index
+    """one zero-initialised device word per (GPU, stream) for the arrival-ticket kernels (they leave it at zero): launches on one
+    stream are ordered and may share it; two streams (two systems, forked graph branches) must not race on one word"""
+    key = (device.index, torch.cuda.current_stream(device).stream_id)
     t = _TICKETS.get(key)
     if t is None:
         t = _TICKETS[key] = torch.zeros(4, device=device, dtype=torch.int32)
@@ -286,6 +316,7 @@ def composite_train_loss(raw, z, rays, noise, noise_std, white_back, target, gra
     if raw.numel() != B * S * 4 or target.numel() != B * 3 or (rgb_coarse is not None and rgb_coarse.numel() != B * 3):
         raise ValueError("composite_train_loss: raw must be (B,S,4), target and rgb_coarse (B,3)")
     noise = None if noise_std == 0 else (_c(noise) if noise is not None else None)
+    _check_draw("composite_train_loss", "noise", noise, B * S)
     dev = z.device
     opacity = torch.empty(B, device=dev, dtype=torch.float32)
     rgb = torch.empty(B, 3, device=dev, dtype=torch.float32)
@@ -487,6 +518,9 @@ def mlp_fwd_rays_coarse(rays, n_samples, packed, sigma_only, dtype, use_disp=Fal
         if perturb_rand is None:
             raise ValueError("perturb>0 needs perturb_rand")
         perturb_rand = _c(perturb_rand)
+        if perturb_rand.numel() != B * S or perturb_rand.dtype != torch.float32:
+            raise ValueError("mlp_fwd_rays_coarse: perturb_rand must hold B*S = %d fp32 draws, got %s %s"
+                             % (B * S, tuple(perturb_rand.shape), perturb_rand.dtype))
     z = torch.empty(B, S, device=rays.device, dtype=torch.float32)
     out = torch.empty((B, S) if sigma_only else (B, S, 4), device=rays.device, dtype=torch.float32)
     check(_lib.load().nerfhip_mlp_fwd_rays_coarse(ptr(rays), ptr(perturb_rand if perturb > 0 else None), ptr(z), B, S,

@@ -29,6 +29,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.flats = []
         for m in self.models:
             self.flats.append(torch.nn.Parameter(self._flatten(m), requires_grad=True))
+            m._serial_tracked = True      # this optimizer announces every update (_bump_serial): weight images packed AHEAD of a
+                                          # step (RayStore.sample(pack_models=...)) may be trusted while the serial stands
         super().__init__(self.flats, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = self.flats[0].device
         if not self.flats[0].is_cuda:

@@ -296,9 +296,9 @@ class GraphedTrainStep:
             err = None
             try:
                 self.graph, self.static_out = self._capture_with_draws(lambda: self._eager(self.static_batch))
-            except RuntimeError as e:       # what a failed stream capture / a collective that cannot be captured raises
-                if self.grad_sync is None:
-                    raise
+            except Exception as e:          # a failed stream capture / a collective that cannot be captured (RuntimeError), or
+                if self.grad_sync is None:  # anything else one rank raises: its peers are about to enter agree_any and must not
+                    raise                   # be left blocked in that collective
                 err = e
             # A communicator whose collectives cannot be captured on this stack: keep the collectives outside the graphs
             # instead.  EVERY rank must take the same branch (one rank replaying a captured all-reduce while another issues an

@@ -28,6 +28,7 @@ from oracle import nerf_oracle as O  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "reference_golden.npz")
+OUT_GRADS = os.path.join(ROOT, "tests", "golden", "reference_golden_grads.npz")   # gr3: all 48 gradient tensors in full
 
 
 class _ReplayTorch:
@@ -87,6 +88,7 @@ def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     nerf, rend, calls, replay = build_reference()
     G = {}
+    GFULL = {}
 
     # ---------------------------------------------------------------- 1. Embedding (nerf.py:21-38)
     g = torch.Generator().manual_seed(101)
@@ -243,6 +245,10 @@ def main():
         G[f"{prefix}_full_f_rgb.0.weight"] = mf.rgb[0].weight.grad.clone()
         G[f"{prefix}_full_f_xyz_encoding_1.0.bias"] = getattr(mf, "xyz_encoding_1")[0].bias.grad.clone()
         G[f"{prefix}_full_f_dir_encoding.0.weight"] = mf.dir_encoding[0].weight.grad.clone()
+        if prefix == "gr3":         # configs[2]: EVERY gradient tensor of both models in full (a file of its own: 4.8 MB of fp32)
+            for tag, mod in (("c", mc), ("f", mf)):
+                for n, prm in mod.named_parameters():
+                    GFULL[f"gr3_grad_{tag}_{n}"] = prm.grad.clone()
         # the oracle restatement reproduces these gradients (autograd through nerf_oracle.render_rays)
         opc = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
         opf = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
@@ -275,6 +281,9 @@ def main():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "%.1f KB" % (os.path.getsize(OUT) / 1024), len(out), "arrays")
+    full = {k: v.detach().numpy() for k, v in GFULL.items()}
+    np.savez_compressed(OUT_GRADS, **full)
+    print("wrote", OUT_GRADS, "%.1f KB" % (os.path.getsize(OUT_GRADS) / 1024), len(full), "arrays")
 
 
 if __name__ == "__main__":

@@ -156,14 +156,89 @@ def searchsorted_right(cdf, u):
 
 
 # ----------------------------------------------------------------------------- a8: sample_pdf
-def pdf_to_cdf(weights, eps=1e-5, total_ulp=0):
+def _aten_multi_row_sum(load, nrows, size, zero):
+    """ATen SumKernel.cpp multi_row_sum: `size` steps over `nrows` interleaved fp32 accumulators with a 4-level cascade
+    (level step 16 below 2^20 steps).  load(i, k) -> the k-th row's term of step i."""
+    f = np.float32
+    num_levels = 4
+    ceil_log2 = 0 if size <= 1 else int(size - 1).bit_length()
+    level_power = max(4, ceil_log2 // num_levels)
+    level_step = 1 << level_power
+    level_mask = level_step - 1
+    acc = [[zero.copy() for _ in range(nrows)] for _ in range(num_levels)]
+    i = 0
+    while i + level_step <= size:
+        for _ in range(level_step):
+            for k in range(nrows):
+                acc[0][k] = (acc[0][k] + load(i, k)).astype(f)
+            i += 1
+        for j in range(1, num_levels):
+            for k in range(nrows):
+                acc[j][k] = (acc[j][k] + acc[j - 1][k]).astype(f)
+                acc[j - 1][k] = zero.copy()
+            if (i & (level_mask << (j * level_power))) != 0:
+                break
+    while i < size:
+        for k in range(nrows):
+            acc[0][k] = (acc[0][k] + load(i, k)).astype(f)
+        i += 1
+    for j in range(1, num_levels):
+        for k in range(nrows):
+            acc[0][k] = (acc[0][k] + acc[j][k]).astype(f)
+    return acc[0]
+
+
+def aten_row_total(row):
+    """fp32 `torch.sum` of one contiguous row as ATen's CPU kernel orders the additions (torch 2.x SumKernel.cpp: cascade_sum ->
+    vectorized_inner_sum -> row_sum).  The vectors are 8 floats wide on every x86 capability (checked here under AVX512, AVX2
+    and DEFAULT dispatch: tests/test_oracle_golden.py), rows shorter than one vector take the same path with 1-float vectors:
+    four interleaved vector accumulators over groups of four vectors, the left-over vectors into accumulator 0, accumulators
+    1-3 added to 0, then a scalar chain  0 + row tail + the 8 vector lanes in order.  Restated because the reference's
+    searchsorted indices (rendering.py:42) have knife edges on the LAST BIT of this total (rendering.py:30): the HIP kernels'
+    NERFHIP_ROW_TOTAL_ATEN mode performs exactly these additions."""
+    f = np.float32
+    row = np.asarray(row, f)
+    M = len(row)
+    V = 8 if M >= 8 else 1
+    vs = M // V
+    n_ilp = vs // 4
+    zero = np.zeros(V, f)
+
+    def vec(i):
+        return row[i * V:(i + 1) * V]
+    ps = _aten_multi_row_sum(lambda i, k: vec(4 * i + k), 4, n_ilp, zero) if n_ilp > 0 else [zero.copy() for _ in range(4)]
+    for i in range(n_ilp * 4, vs):
+        ps[0] = (ps[0] + vec(i)).astype(f)
+    for k in range(1, 4):
+        ps[0] = (ps[0] + ps[k]).astype(f)
+    if V == 1:
+        return f(ps[0][0])
+    acc = f(0)
+    for k in range(vs * V, M):
+        acc = f(acc + row[k])
+    for k in range(V):
+        acc = f(acc + ps[0][k])
+    return acc
+
+
+def pdf_to_cdf(weights, eps=1e-5, total_ulp=0, total="torch"):
     """rendering.py:29-33.  torch-CPU cumsum on fp32 (fp64 running sum rounded per element,
     SURVEY A.9) is kept because that IS the oracle's arithmetic.
-    `total_ulp` shifts the fp32 row total by that many ulps: torch.sum's fp32 reduction order is
-    platform dependent (SIMD width), and the reference algorithm has knife edges (u == 1.0 in det
-    mode, `denom < eps`) that flip on that last bit; tests accept any shift in [-2, 2]."""
+    `total`: "torch" = torch.sum itself (the reference's line); "aten" = aten_row_total, the restatement of its addition
+    order (bit-equal to "torch" on a CPU); "exact" = the correctly rounded sum (what the HIP kernels use by default).
+    `total_ulp` shifts the fp32 row total by that many ulps: torch.sum's fp32 reduction order differs from the correctly
+    rounded sum in the last bit, and the reference algorithm has knife edges (u == 1.0 in det
+    mode, `denom < eps`) that flip on that last bit; tests of the default mode accept any shift in [-2, 2]."""
     w = weights.float() + eps
-    total = torch.sum(w, -1, keepdim=True)
+    if total == "torch":
+        tot = torch.sum(w, -1, keepdim=True)
+    elif total == "aten":
+        tot = torch.from_numpy(np.array([aten_row_total(r) for r in w.contiguous().numpy()], np.float32))[:, None]
+    elif total == "exact":
+        tot = w.double().sum(-1, keepdim=True).float()
+    else:
+        raise ValueError(total)
+    total = tot
     for _ in range(abs(int(total_ulp))):
         total = torch.nextafter(total, torch.full_like(total, math.inf if total_ulp > 0 else -math.inf))
     pdf = w / total
@@ -171,11 +246,11 @@ def pdf_to_cdf(weights, eps=1e-5, total_ulp=0):
     return torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
 
 
-def sample_pdf(bins, weights, n_importance, u=None, eps=1e-5, return_aux=False, total_ulp=0):
+def sample_pdf(bins, weights, n_importance, u=None, eps=1e-5, return_aux=False, total_ulp=0, total="torch"):
     """Inverse-CDF sampling, rendering.py:14-55.  u=None -> deterministic linspace (:36-37),
     else the injected (B,N_i) uniform draws (:39)."""
     B, M = weights.shape
-    cdf = pdf_to_cdf(weights, eps, total_ulp)
+    cdf = pdf_to_cdf(weights, eps, total_ulp, total)
     if u is None:
         u = torch.linspace(0, 1, n_importance).expand(B, n_importance)
     u = u.contiguous().float()

@@ -36,6 +36,13 @@ def golden():
     return out
 
 
+@pytest.fixture(scope="session")
+def golden_grads():
+    """gr3 (BASELINE configs[2] shape): all 48 gradient tensors of the reference's training loss, in full (oracle/make_golden.py)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_golden_grads.npz"), allow_pickle=False)
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
 def has_gpu():
     return torch.cuda.is_available()
 

@@ -147,3 +147,58 @@ def test_reduced_precision_gradient_direction(dev, n):
     for dt in worst_rel:
         assert worst_rel[dt][0] <= REL_L2_MAX[dt], (dt, n, worst_rel[dt])
         assert abs(worst_ratio[dt][0] - 1) <= NORM_RATIO_MAX[dt], (dt, n, worst_ratio[dt])
+
+
+# Gates of the test below, per gradient tensor of both models (48): measured maxima in the comment of each line
+TIMED_NODE_BOUNDS = {"bf16": dict(cos=0.99, rel_l2=0.15, loss_rel=5e-3, rgb_abs=2e-2),
+                     "bf16_f8": dict(cos=0.98, rel_l2=0.22, loss_rel=5e-3, rgb_abs=2e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "bf16_f8"])
+def test_timed_node_at_benchmark_size_vs_oracle_gradients(dev, dtype):
+    """The node bench.py times (models/train_step.render_rays_train: fused launches, one autograd node) in the HEADLINE arithmetic
+    (bf16 MFMA, fp32 accumulate) at the HEADLINE size — 1024 rays x (64 + 128) samples, perturb = 1, noise_std = 0, white
+    background (BASELINE configs[2]) — against autograd through the fp32 CPU oracle on the same rays, weights and draws: loss,
+    rendered colours and every one of the 48 gradient tensors (direction AND magnitude: cosine, relative L2 error).
+    The oracle runs the 262,144 points in four ray chunks (the loss is a mean over rays: chunk losses add)."""
+    from helpers import fused_draws
+    from nerf_pl_amd.models.train_step import render_rays_train
+    Bn, Sc, Ni, seed = 1024, 64, 128, 3100
+    kw = dict(N_samples=Sc, use_disp=False, perturb=1.0, noise_std=0.0, N_importance=Ni, white_back=True, test_time=False)
+    params = [O.make_params(seed, 6.0, 0.3), O.make_params(seed + 500, 6.0, 0.3)]
+    rays = O.make_rays(seed, Bn, "blender")
+    rng = O.draw_rng(seed, Bn, Sc, Ni, 1.0)
+    tgt = torch.rand(Bn, 3, generator=torch.Generator().manual_seed(seed))
+    # ---- oracle: fp32 autograd on the CPU, 256 rays at a time
+    op = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+    ref_loss, ref_rgb = 0.0, []
+    for lo in range(0, Bn, 256):
+        sl = slice(lo, lo + 256)
+        res = O.render_rays(op, rays[sl], Sc, False, 1.0, 0.0, Ni, True, False, rng={k: v[sl] for k, v in rng.items()})
+        part = O.mse_loss(res, tgt[sl]) * (256.0 / Bn)
+        part.backward()
+        ref_loss += part.item()
+        ref_rgb.append(res["rgb_fine"].detach())
+    ref_rgb = torch.cat(ref_rgb)
+    # ---- the timed node
+    ms, emb = build_models(params, dev, dtype)
+    res, loss, out3 = render_rays_train(ms, emb, rays.to(dev), tgt.to(dev), Sc, False, 1.0, 0.0, Ni, True, draws=fused_draws(rng, kw, dev))
+    loss.backward()
+    bd = TIMED_NODE_BOUNDS[dtype]
+    loss_rel = abs(loss.item() - ref_loss) / abs(ref_loss)
+    rgb_abs = (res["rgb_fine"].cpu() - ref_rgb).abs().max().item()
+    worst_cos, worst_rel = (1.0, ""), (0.0, "")
+    for tag, m, o in (("c", ms[0], op[0]), ("f", ms[1], op[1])):
+        for n, prm in m.named_parameters():
+            g, r = prm.grad.cpu().flatten(), o[n].grad.flatten()
+            cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+            rel = (g - r).norm().item() / (r.norm().item() + 1e-20)
+            if cos < worst_cos[0]:
+                worst_cos = (cos, tag + "." + n)
+            if rel > worst_rel[0]:
+                worst_rel = (rel, tag + "." + n)
+            assert cos >= bd["cos"] and rel <= bd["rel_l2"], (dtype, tag, n, cos, rel)
+    print("timed node %s @ 1024 x (64+128) vs fp32 oracle: loss rel err %.2e, rgb_fine max abs err %.2e, worst gradient cosine %.4f (%s), "
+          "worst relative L2 error %.4f (%s)" % (dtype, loss_rel, rgb_abs, worst_cos[0], worst_cos[1], worst_rel[0], worst_rel[1]))
+    assert loss_rel <= bd["loss_rel"], (loss.item(), ref_loss)
+    assert rgb_abs <= bd["rgb_abs"], rgb_abs

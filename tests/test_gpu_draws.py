@@ -184,6 +184,98 @@ def test_captured_draws_walk_the_generator_stream(dev):
     assert torch.equal(outs[0], nxt)
 
 
+def test_replica_self_check_and_torch_fallback(dev):
+    """draws.replica_ok: the first use on a device checks the Philox replica against torch's own rand / randn / randint (values and
+    generator offsets, two private generators) — it must hold on this torch build and leave the default generator untouched.
+    With the replica declared broken (what the check does on a torch that moved its stream; NERFHIP_DRAWS=torch) every entry
+    point makes the same tensors through torch's own calls: RayStore.sample with the step's draws and the weight images is bit
+    for bit the replica's, the generator ends at the same offset."""
+    from nerf_pl_amd import draws as D
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    torch.manual_seed(41)
+    off0 = _gen(dev).get_offset()
+    D._REPLICA.pop(idx, None)
+    assert D._self_check(dev) is True
+    assert D.replica_ok(dev) is True and D._REPLICA[idx] is True
+    assert _gen(dev).get_offset() == off0            # private generators: the default stream has not moved
+    st = _store(dev)
+    models = _models(dev, "bf16")
+    B, S, N = 300, 64, 128
+    torch.manual_seed(9)
+    want = st.sample(B, step_draws=(S, N, 1.0, 1.0), return_ids=True, pack_models=(models, "bf16"))
+    want_packs = [tuple(b.clone() for b in m.train_buffers("bf16", dev)) for m in models]
+    off = _gen(dev).get_offset()
+    for m in models:
+        for buf in m.train_buffers("bf16", dev):
+            buf.zero_()
+    try:
+        D._REPLICA[idx] = False
+        torch.manual_seed(9)
+        got = st.sample(B, step_draws=(S, N, 1.0, 1.0), return_ids=True, pack_models=(models, "bf16"))
+        assert _gen(dev).get_offset() == off
+        assert torch.equal(got["ids"], want["ids"]) and torch.equal(got["rays"], want["rays"]) and torch.equal(got["rgbs"], want["rgbs"])
+        assert set(got["draws"]) == set(want["draws"])
+        for k, v in want["draws"].items():
+            assert torch.equal(got["draws"][k], v), k
+        for m, wp in zip(models, want_packs):
+            for a, b in zip(m.train_buffers("bf16", dev), wp):
+                assert torch.equal(a, b)
+        # unread draws still advance the stream; the ids need not be returned
+        torch.manual_seed(9)
+        got2 = st.sample(B, step_draws=(S, N, 1.0, 0.0))
+        assert _gen(dev).get_offset() == off and "ids" not in got2 and "noise_coarse" not in got2["draws"]
+        assert torch.equal(got2["rays"], want["rays"]) and torch.equal(got2["draws"]["u"], want["draws"]["u"])
+        assert not D.in_graph_stream(dev)
+    finally:
+        D._REPLICA[idx] = True
+
+
+def test_modular_step_and_batch_source_share_one_captured_stream(dev):
+    """(round-4 advisor finding) A captured step that mixes draws.py launches — the batch source, RayStore.sample — with the
+    MODULAR render_rays (rendering.py's four rand / randn calls): inside the capture those four come from the same device-resident
+    generator state as the batch's randint, so replay k consumes exactly what the k-th eager step would — torch's own
+    capture-time bookkeeping would have restarted the render draws at the offset the batch's randint starts from (correlated
+    pixel ids and jitter) and after_replay would have overwritten its advance."""
+    from argparse import Namespace
+    from nerf_pl_amd.system import GraphedTrainStep, NeRFSystem
+    hp = Namespace(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=1.0, chunk=32768, loss_type="mse", lr=5e-4,
+                   weight_decay=0, decay_step=[10 ** 9], decay_gamma=0.5, white_back=True, optimizer="adam", lr_scheduler="steplr")
+    st = _store(dev)
+    B, steps = 256, 7
+
+    def run(graphed):
+        system = NeRFSystem(hp)
+        system.nerf_coarse.load_state_dict(O.make_params(5, 4.0, 0.2))
+        system.nerf_fine.load_state_dict(O.make_params(6, 4.0, 0.2))
+        for m in system.models:
+            m.mlp_dtype = "fp32"
+        system.fused_train_step = False                       # the modular graph: render_rays + MSELoss, torch-style draws
+        system = system.to(dev)
+        (opt,), _ = system.configure_optimizers()
+        torch.manual_seed(123)
+        losses = []
+        if graphed:
+            stepper = GraphedTrainStep(system, opt, warmup=2, batch_source=lambda: st.sample(B))
+            for _ in range(steps):
+                losses.append(stepper()["loss"].clone())
+        else:
+            for i in range(steps):
+                out = system.training_step(st.sample(B), i)
+                opt.zero_grad(set_to_none=True)
+                out["loss"].backward()
+                opt.step()
+                losses.append(out["loss"].detach().clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), _gen(dev).get_offset(), [p.detach().clone() for p in system.parameters()]
+
+    l_e, off_e, p_e = run(False)
+    l_g, off_g, p_g = run(True)
+    assert off_e == off_g, (off_e, off_g)
+    assert torch.equal(l_e, l_g), (l_e, l_g)
+    for a, b in zip(p_e, p_g):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------------- the fused launches
 def _models(dev, dtype, seeds=(5, 6)):
     from helpers import build_models

@@ -43,7 +43,7 @@ def make_data(dev, **scene):
     return rays, rgbs, rays_val, rgb_val
 
 
-def train_curve(dtype, dev, data, init, jitter_seed, steps=STEPS, lr_at=LR_AT, eval_at=EVAL_AT, dead_check=None):
+def train_curve(dtype, dev, data, init, jitter_seed, steps=STEPS, lr_at=LR_AT, eval_at=EVAL_AT, dead_check=None, N=N):
     """One training run of `steps` 1024-ray steps; returns {step: PSNR on the held-out rays}, or None when `dead_check` =
     (step, dB) finds the run still under `dB` at `step`."""
     from nerf_pl_amd.inference import batched_inference
@@ -128,6 +128,19 @@ def test_psnr_within_0p1_db_of_fp32_at_equal_steps(dev):
     assert 29.5 <= res["mean_psnr"]["fp32"] <= 33.0, res["mean_psnr"]
     for dt, p in res["paired"].items():
         assert p["stderr"] <= 0.05, (dt, p)
+        assert abs(p["mean"]) <= 0.1, (dt, p)
+
+
+def test_psnr_gate_at_the_headline_sampling_64_plus_128(dev):
+    """The same paired gate at the HEADLINE sampling of BASELINE configs[2] — 64 coarse + 128 importance samples, what bench.py
+    times — on 8 live seeds (the 16-seed gate above runs the README recipe's 64 + 64): |mean paired difference| <= 0.1 dB,
+    standard error <= 0.07 dB."""
+    res = paired_statistics(dev, n_live=8, N=128)
+    print("PSNR gate 64+128:", {k: res[k] for k in ("seeds", "dead_seeds", "mean_psnr", "paired")})
+    assert len(res["seeds"]) >= 8, res["dead_seeds"]
+    assert 29.5 <= res["mean_psnr"]["fp32"] <= 33.5, res["mean_psnr"]
+    for dt, p in res["paired"].items():
+        assert p["stderr"] <= 0.07, (dt, p)
         assert abs(p["mean"]) <= 0.1, (dt, p)
 
 

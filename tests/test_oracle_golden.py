@@ -34,6 +34,25 @@ def test_cdf_bit_exact(golden):
     assert torch.equal(O.pdf_to_cdf(golden["sp_w"]), golden["ss_rand_cdf"])
 
 
+def test_aten_row_total_restatement(golden):
+    """oracle.aten_row_total (the addition order the HIP kernels' NERFHIP_ROW_TOTAL_ATEN mode performs) IS torch.sum on a CPU:
+    against torch.sum itself over row lengths that exercise the scalar path (< 8), the tail, the leftover vectors and the
+    16-step cascade (>= 512), and against the reference-minted cdf vectors (rendering.py:29-33 recorded at the call site)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(11)
+    for M in (1, 3, 7, 8, 9, 31, 62, 63, 64, 127, 190, 511, 512, 640, 1023, 2040):
+        w = torch.rand(24, M, generator=g) ** 4 + 1e-5
+        want = torch.sum(w, -1).numpy()
+        got = np.array([O.aten_row_total(r) for r in w.numpy()], np.float32)
+        assert np.array_equal(want, got), M
+    w = golden["sp_w"].float() + 1e-5
+    assert np.array_equal(torch.sum(w, -1).numpy(), np.array([O.aten_row_total(r) for r in w.numpy()], np.float32))
+    assert torch.equal(O.pdf_to_cdf(golden["sp_w"], total="aten"), golden["ss_det64_cdf"])
+    # ... and the correctly rounded total (the kernels' default) differs from it in the last bit on a good share of the rows
+    exact = O.pdf_to_cdf(golden["sp_w"], total="exact")
+    assert 0.2 < (exact == golden["ss_det64_cdf"]).all(-1).float().mean().item() < 0.9
+
+
 def test_sample_pdf(golden):
     bins, w = golden["sp_bins"], golden["sp_w"]
     for n in (64, 128):
@@ -85,3 +104,26 @@ def test_training_gradients(golden):
             assert (dig - ref).abs().max().item() <= 2e-4 * scale + 1e-9, (tag, n, dig, ref)
     assert torch.allclose(pc["sigma.weight"].grad, golden["gr_full_c_sigma.weight"], rtol=1e-3, atol=1e-7)
     assert torch.allclose(pf["rgb.0.weight"].grad, golden["gr_full_f_rgb.0.weight"], rtol=1e-3, atol=1e-7)
+
+
+def test_training_gradients_gr3_all_tensors_in_full(golden, golden_grads):
+    """configs[2] shape (64 + 128 samples, perturb = 1, noise_std = 0, white background): autograd through the oracle against ALL
+    48 gradient tensors of the reference, element for element (2e-5 of each tensor's max |g|; the two differ in torch op
+    fusion only)."""
+    from tests.helpers import case_from_golden
+    params, rays, kw, rng = case_from_golden(golden, None, prefix="gr3")
+    for d in params:
+        for v in d.values():
+            v.requires_grad_(True)
+    kw = dict(kw)
+    res = O.render_rays(params, rays, kw["N_samples"], kw["use_disp"], kw["perturb"], kw["noise_std"], kw["N_importance"],
+                        kw["white_back"], False, rng=rng)
+    O.mse_loss(res, golden["gr3_target"]).backward()
+    assert len(golden_grads) == 48
+    for tag, d in (("c", params[0]), ("f", params[1])):
+        for n, v in d.items():
+            ref = golden_grads[f"gr3_grad_{tag}_{n}"]
+            assert ref.shape == v.grad.shape
+            assert (v.grad - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-10, (tag, n)
+            # the digests of the main golden file are digests of these very tensors
+            assert torch.equal(O.grad_digest(ref), golden[f"gr3_{tag}_{n}"])
