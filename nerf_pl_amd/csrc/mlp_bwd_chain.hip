@@ -479,7 +479,7 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
     sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, lds_lo, lds_hi, sig_lds, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
                                                        f8_dy_section(dy_h(8)), kDyFeat, sb, lane);
     // ---- layers 3..8 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
-    // straight-line code against a 64 KiB instruction cache (profiles/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel
+    // straight-line code against a 64 KiB instruction cache (profiles/archive/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel
     // over that size runs 1.5x slower for its instruction fetches alone).  A 256 x 256 layer is 4 chunks of the W^T stream, so
     // three layers later the stream is at the same piece offset within a chunk AND in the same ring slot (12 chunks = 0 mod 3):
     // the second pass differs only in wave-uniform values — the stream pointer (+12 chunks), the gate piece (-3), the dY

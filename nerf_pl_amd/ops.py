@@ -106,12 +106,16 @@ def searchsorted(a, v, out=None, side="left"):
     return out
 
 
-# Rounding of sample_pdf's normaliser `torch.sum(weights, -1)` (rendering.py:30; include/nerfhip.h NERFHIP_ROW_TOTAL_*): "exact" =
-# the correctly rounded fp32 sum (host-independent, the default), "aten" = the reference's own bits on a CPU (ATen's fp32
-# addition order), under which the searchsorted indices recorded at the reference's call site are reproduced on every element.
-# Process-wide (every sample_pdf / fine_z / fused training launch reads it at call time); NERFHIP_ROW_TOTAL=aten in the environment.
+# Rounding of sample_pdf's normaliser `torch.sum(weights, -1)` (rendering.py:30; include/nerfhip.h NERFHIP_ROW_TOTAL_*):
+#   "aten"  (default) the reference's own bits: ATen's fp32 addition order on a CPU.  The searchsorted indices of rendering.py:42
+#           have knife edges on the last bit of this total; under this mode the (cdf, u) -> inds triples recorded at the
+#           reference's call site are reproduced on EVERY element, and the fine model's gradients agree with the reference's to
+#           ~1e-6 of each tensor's maximum instead of ~1e-2 (0.1-0.5 % of the fine samples land in another bin otherwise:
+#           tests/test_gpu_training.py).  Costs ~30 dependent fp32 additions per ray.
+#   "exact" the correctly rounded fp32 sum (host-independent); what the plain C entry points nerfhip_sample_pdf / nerfhip_fine_z use.
+# Process-wide (every sample_pdf / fine_z / fused training launch reads it at call time); NERFHIP_ROW_TOTAL=exact in the environment.
 _ROW_TOTAL_MODES = {"exact": 0, "aten": 1}
-_row_total = _ROW_TOTAL_MODES[os.environ.get("NERFHIP_ROW_TOTAL", "exact")]
+_row_total = _ROW_TOTAL_MODES[os.environ.get("NERFHIP_ROW_TOTAL", "aten")]
 
 
 def set_row_total(mode):

@@ -7,6 +7,7 @@ nn.Module otherwise (Lightning is not installed in this image; `fit()` below is 
 for Trainer.fit used by tests and bench — harness, not product).
 Datasets are injected (`train_dataset` / `val_dataset`): dataset I/O is out of scope.
 """
+import os
 from collections import defaultdict
 
 import torch
@@ -203,14 +204,15 @@ class GraphedTrainStep:
     time.  The first `warmup` calls run eagerly on the real batches (they are ordinary training steps), the next call
     captures and then replays.  A learning-rate change (scheduler) triggers a re-capture.
 
-    With a `grad_sync` (N > 1 ranks) the step is by default ONE graph too: the all-reduces the grad-ready hooks issue are
-    captured inside it (RCCL supports capture) and overlap the rest of the backward on replay.  `sync_in_graph=False`
-    captures TWO graphs — [forward + backward] and [optimizer] — with the all-reduce of the two flat gradient buffers issued
-    eagerly in between.  World-1 A/B on one MI355X (RCCL communicator of one rank, profiles/README.md round 3): one graph
+    With a `grad_sync` (N > 1 ranks) the step is by default TWO graphs — [forward + backward] and [optimizer] — with the
+    all-reduce of the two flat gradient buffers issued eagerly in between.  `sync_in_graph=True` (or NERFHIP_SYNC_IN_GRAPH=1)
+    makes it ONE graph: the all-reduces the grad-ready hooks issue are captured inside it (RCCL supports capture) and overlap
+    the rest of the backward on replay; opt-in until a real N > 1 run has validated it (it falls back to two graphs, agreed
+    across the ranks, when the capture fails).  World-1 A/B on one MI355X (RCCL communicator of one rank, profiles/README.md round 3): one graph
     0.957 ms, two graphs 0.982 ms, no communicator 0.908 ms per step.
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
-    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=True, backend=None, batch_source=None):
+    def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=None, backend=None, batch_source=None):
         self.system, self.opt, self.grad_sync = system, optimizer, grad_sync
         # `batch_source`: a callable returning the next {'rays', 'rgbs'} batch from device-resident data (RayStore.sample with
         # the default generator).  It is then called INSIDE the step, i.e. captured into the graph: every replay draws a fresh
@@ -218,7 +220,13 @@ class GraphedTrainStep:
         self.batch_source = batch_source
         self._seed = None
         self.warmup = warmup
-        self.sync_in_graph = sync_in_graph
+        # N > 1 ranks: TWO graphs with the all-reduces issued eagerly in between is the default — the form whose every piece has
+        # run on hardware (hipGraph replay at world 1, eager RCCL all-reduce).  ONE graph with the collectives captured inside
+        # (sync_in_graph=True, NERFHIP_SYNC_IN_GRAPH=1; 25 us faster at world 1) has never met a real N > 1 communicator — no
+        # multi-GPU node was available to any round — so it is opt-in until a hardware run has validated it.
+        if sync_in_graph is None:
+            sync_in_graph = os.environ.get("NERFHIP_SYNC_IN_GRAPH", "0") == "1"
+        self.sync_in_graph = bool(sync_in_graph)
         self.calls = 0
         self.graph = None
         self.graph_opt = None

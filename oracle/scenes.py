@@ -12,7 +12,7 @@ neither the HIP path nor the oracle.
   PSNR at ~32.6 dB and fp32 training ends at 31.3 dB — the reference's lego range (README.md:161: 31.39 dB;
   test.ipynb:132: 30.65 dB), the regime in which `north_star` asks for "PSNR within 0.1 dB of the reference at equal steps".
   `grain=0` removes the plateau: the same recipe is then still climbing at 30-31 dB and trajectory chaos (+-0.6 dB per run
-  pair) swamps any arithmetic effect (profiles/r03_psnr_gate_brick_no_grain.json).
+  pair) swamps any arithmetic effect (profiles/archive/r03_psnr_gate_brick_no_grain.json).
 """
 import torch
 

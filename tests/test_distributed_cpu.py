@@ -115,11 +115,13 @@ def _graphed_step_host_logic(rank, world):
         ropt.step()
     rflat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
     ok = bool(ok and torch.allclose(flat, rflat, rtol=1e-5, atol=1e-6))
-    # the DEFAULT N > 1 form: ONE graph with the collectives inside (issued by sync() during the captured step) — same replicas
+    # the default IS the two-graph form (one graph is opt-in until a real N > 1 run has validated it)
+    ok = ok and GraphedTrainStep(sysm, opt, grad_sync=sync, backend=_RecordingBackend())._two_graphs()
+    # the opt-in N > 1 form: ONE graph with the collectives inside (issued by sync() during the captured step) — same replicas
     sys1 = _TinySystem()
     opt1 = torch.optim.SGD(sys1.parameters(), lr=0.1)
     be1 = _RecordingBackend()
-    step1 = GraphedTrainStep(sys1, opt1, grad_sync=parallel.GradSync(sys1.models), warmup=2, backend=be1)
+    step1 = GraphedTrainStep(sys1, opt1, grad_sync=parallel.GradSync(sys1.models), warmup=2, backend=be1, sync_in_graph=True)
     for i, b in enumerate(batches):
         if i == 5:
             for grp in opt1.param_groups:
@@ -140,7 +142,7 @@ def _graphed_step_host_logic(rank, world):
             return super().capture(fn, share_pool_with)
 
     be2 = _NoCollectiveInGraph()
-    step2 = GraphedTrainStep(sys2, opt2, grad_sync=parallel.GradSync(sys2.models), warmup=2, backend=be2)
+    step2 = GraphedTrainStep(sys2, opt2, grad_sync=parallel.GradSync(sys2.models), warmup=2, backend=be2, sync_in_graph=True)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -161,10 +163,10 @@ def _graphed_step_host_logic(rank, world):
     class _Rank1CannotCapture(_RecordingBackend):
         def capture(self, fn, share_pool_with=None):
             if rank == 1 and getattr(fn, "__name__", "") == "<lambda>" and "_eager" in fn.__code__.co_names:
-                raise RuntimeError("capture failed on this rank only")
+                raise ValueError("capture failed on this rank only (not a RuntimeError: the peer must still not be left waiting)")
             return super().capture(fn, share_pool_with)
 
-    step3 = GraphedTrainStep(sys3, opt3, grad_sync=parallel.GradSync(sys3.models), warmup=2, backend=_Rank1CannotCapture())
+    step3 = GraphedTrainStep(sys3, opt3, grad_sync=parallel.GradSync(sys3.models), warmup=2, backend=_Rank1CannotCapture(), sync_in_graph=True)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for i, b in enumerate(batches):
@@ -368,3 +370,37 @@ def test_graphed_step_batch_source_host_logic():
         stepper({"x": torch.zeros(16, 5), "y": torch.zeros(16, 3)})
     with pytest.raises(ValueError):
         GraphedTrainStep(sysm, opt, warmup=2, backend=_RecordingBackend())()
+
+
+def _torchrun(nproc, script_args, timeout=180):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "host", "bench_rank_logic.py")] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=root)
+
+
+def test_bench_rank_logic_world2_gloo_end_to_end():
+    """bench.py's own launch-contract functions under the launcher the driver uses (torch.distributed.run, 2 processes, gloo):
+    init_world sees a 2-rank communicator, timed_region reports the SLOWER rank's time (rank 1 sleeps twice as long), the
+    sharded image equals the unsharded one, and exactly one JSON line comes out (rank 0's)."""
+    import json
+    r = _torchrun(2, ["2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_nranks"] == 2 and d["sharded_equal"] and d["span"] == [0, 501]
+    assert 5 * 0.04 * 0.95 <= d["dt"] <= 5 * 0.04 * 3, d["dt"]          # 5 steps of rank 1's 40 ms, not rank 0's 20 ms
+
+
+def test_bench_rank_logic_refuses_a_world_that_is_not_gpus():
+    """2 processes launched, --gpus 4 requested: every rank exits 2 before any group is formed, no line."""
+    r = _torchrun(2, ["4"])
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "WORLD_SIZE=2 but --gpus 4" in r.stderr

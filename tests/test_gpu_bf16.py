@@ -61,13 +61,13 @@ def test_psnr_at_equal_steps_vs_fp32(dev):
     """PSNR@step of the reduced-precision configurations against the fp32 path: same init, same batches, same RNG draws.
 
     Training is chaotic: a single trajectory pair says little — the CPU oracle run on two hosts (same code, seeds and
-    batches) is 0.9 dB apart by step 200 (profiles/r02_oracle_curve.json), two fp32 runs here that differ in the jitter seed
+    batches) is 0.9 dB apart by step 200 (profiles/archive/r02_oracle_curve.json), two fp32 runs here that differ in the jitter seed
     0.1-0.4 dB, and changing nothing but the split-K partition of the fp32 dW reduction (a different fp32 summation order)
     moved the fp32 curves themselves by 0.03-0.27 dB and the per-seed bf16 - fp32 difference between -1.46 and +0.40 dB.
     A bare `|delta| <= 0.1 dB` on one pair would therefore test the seed, not the arithmetic.  This test is the 60-second
     guard against GROSS degradation (an e4m3 dY cost 1.05 dB over three seeds): over four init/jitter seeds and the three
     post-decay checkpoints, the mean PSNR of every reduced-precision configuration is within 1.0 dB of fp32's (standard error
-    of that mean ~0.3 dB); the statistics proper are in profiles/r02_psnr_seeds_final.json (tests/tools/psnr_seeds.py: bf16
+    of that mean ~0.3 dB); the statistics proper are in profiles/archive/r02_psnr_seeds_final.json (tests/tools/psnr_seeds.py: bf16
     -0.27 +- 0.16 dB, bf16_f8 -0.08 +- 0.07 dB vs fp32 at 42.7 dB, four live seeds).  The noise-free half: the SAME weights
     rendered through the bf16 forward and through the fp32 forward agree to 0.1 dB."""
     from nerf_pl_amd.inference import batched_inference
@@ -149,12 +149,19 @@ def test_reduced_precision_gradient_direction(dev, n):
         assert abs(worst_ratio[dt][0] - 1) <= NORM_RATIO_MAX[dt], (dt, n, worst_ratio[dt])
 
 
-# Gates of the test below, per gradient tensor of both models (48): measured maxima in the comment of each line
-TIMED_NODE_BOUNDS = {"bf16": dict(cos=0.99, rel_l2=0.15, loss_rel=5e-3, rgb_abs=2e-2),
-                     "bf16_f8": dict(cos=0.98, rel_l2=0.22, loss_rel=5e-3, rgb_abs=2e-2)}
+# Gates of the test below, per gradient tensor of both models (48).  Measured (r05 call 3, one box): fp32 — cosine 1.00000, relative
+# L2 error <= 1e-4 (coarse) / 5e-3 (fine trunk, with the "exact" row total; ATen order: see the test) ; bf16 — cosine >= 0.9926,
+# relative L2 <= 0.114, bf16_f8 — cosine >= 0.9922, relative L2 <= 0.125, BOTH except the density head (sigma.weight, sigma.bias):
+# its gradient is sum_p g_sigma[p] * h8[p] with h8 >= 0 (post-ReLU) and g_sigma of both signs — samples in front of a surface
+# push the density up, samples behind it down — a sum that cancels to ~1 % of its terms, so the 0.4 % rounding of a bf16 forward
+# moves it by tens of % (norm ratio 1.46 coarse / 0.82 fine) while its direction holds (cosine 0.9926 / 0.9996).  The head is
+# therefore gated on its direction and on its error RELATIVE TO THE TERMS OF THE SUM (sum_p |g_sigma[p]|: `sigma_head_abs`).
+TIMED_NODE_BOUNDS = {"fp32": dict(cos=0.99999, rel_l2=1e-3, loss_rel=1e-5, rgb_abs=1e-4, sigma_head_abs=1e-5),
+                     "bf16": dict(cos=0.99, rel_l2=0.15, loss_rel=1e-3, rgb_abs=2e-3, sigma_head_abs=5e-3),
+                     "bf16_f8": dict(cos=0.99, rel_l2=0.16, loss_rel=1e-3, rgb_abs=2e-3, sigma_head_abs=5e-3)}
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "bf16_f8"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_f8"])
 def test_timed_node_at_benchmark_size_vs_oracle_gradients(dev, dtype):
     """The node bench.py times (models/train_step.render_rays_train: fused launches, one autograd node) in the HEADLINE arithmetic
     (bf16 MFMA, fp32 accumulate) at the HEADLINE size — 1024 rays x (64 + 128) samples, perturb = 1, noise_std = 0, white
@@ -187,18 +194,37 @@ def test_timed_node_at_benchmark_size_vs_oracle_gradients(dev, dtype):
     bd = TIMED_NODE_BOUNDS[dtype]
     loss_rel = abs(loss.item() - ref_loss) / abs(ref_loss)
     rgb_abs = (res["rgb_fine"].cpu() - ref_rgb).abs().max().item()
-    worst_cos, worst_rel = (1.0, ""), (0.0, "")
+    rows = []
     for tag, m, o in (("c", ms[0], op[0]), ("f", ms[1], op[1])):
         for n, prm in m.named_parameters():
             g, r = prm.grad.cpu().flatten(), o[n].grad.flatten()
             cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
             rel = (g - r).norm().item() / (r.norm().item() + 1e-20)
-            if cos < worst_cos[0]:
-                worst_cos = (cos, tag + "." + n)
-            if rel > worst_rel[0]:
-                worst_rel = (rel, tag + "." + n)
-            assert cos >= bd["cos"] and rel <= bd["rel_l2"], (dtype, tag, n, cos, rel)
+            rows.append((tag + "." + n, cos, rel, g.norm().item() / (r.norm().item() + 1e-20), r.norm().item()))
+    worst_cos, worst_rel = min(rows, key=lambda t: t[1]), max(rows, key=lambda t: t[2])
     print("timed node %s @ 1024 x (64+128) vs fp32 oracle: loss rel err %.2e, rgb_fine max abs err %.2e, worst gradient cosine %.4f (%s), "
-          "worst relative L2 error %.4f (%s)" % (dtype, loss_rel, rgb_abs, worst_cos[0], worst_cos[1], worst_rel[0], worst_rel[1]))
+          "worst relative L2 error %.4f (%s)" % (dtype, loss_rel, rgb_abs, worst_cos[1], worst_cos[0], worst_rel[2], worst_rel[0]))
+    print("  per tensor (name, cosine, relative L2 error, norm ratio, |ref|):")
+    for row in rows:
+        print("   %-28s %.5f %.4f %.4f %.3e" % row)
+    # the non-cancelling scale of the density head's gradient: sum_p |d loss / d sigma_p| of each pass (fp32 launches of the
+    # same pieces the node runs)
+    from nerf_pl_amd import ops
+    m32, _ = build_models(params, dev, "fp32")
+    gs = 2.0 / (3 * Bn)
+    rd, td = rays.to(dev), tgt.to(dev)
+    zc, raw_c = ops.mlp_fwd_rays_coarse(rd, Sc, m32[0].packed_weights("fp32"), False, "fp32", False, 1.0, rng["perturb_rand"].to(dev))
+    _, _, _, _, g_raw_c, zf = ops.composite_train_fine_z(raw_c, zc, rd, None, 0.0, True, td, gs, Ni, u=rng["u"].to(dev))
+    raw_f = ops.mlp_fwd_rays(rd, zf, m32[1].packed_weights("fp32"), False, "fp32")
+    g_raw_f = ops.composite_train(raw_f, zf, rd, None, 0.0, True, td, gs, want_weights=False)[4]
+    terms = {"c": g_raw_c[..., 3].abs().sum().item(), "f": g_raw_f[..., 3].abs().sum().item()}
+    for tag, m, o in (("c", ms[0], op[0]), ("f", ms[1], op[1])):
+        gb, rb = m.sigma.bias.grad.cpu().item(), o["sigma.bias"].grad.item()
+        print("  %s density head: sum_p g_sigma = %.3e (oracle %.3e), sum_p |g_sigma| = %.3e -> cancellation x%.0f, error / terms %.2e"
+              % (tag, gb, rb, terms[tag], terms[tag] / abs(rb), abs(gb - rb) / terms[tag]))
+        assert abs(gb - rb) <= bd["sigma_head_abs"] * terms[tag], (dtype, tag, gb, rb, terms[tag])
+    for name, cos, rel, _, _ in rows:
+        head = name.endswith(("sigma.weight", "sigma.bias"))
+        assert cos >= bd["cos"] and (head or rel <= bd["rel_l2"]), (dtype, name, cos, rel)
     assert loss_rel <= bd["loss_rel"], (loss.item(), ref_loss)
     assert rgb_abs <= bd["rgb_abs"], rgb_abs

@@ -5,15 +5,15 @@ No dataset is available offline, so the scene is the procedural lego-like `oracl
 with a hard-edged checker texture plus a fine grain above the bandwidth of the positional encoding (unrepresentable detail:
 what makes a real scene plateau); PSNR@step ends at ~31.3 dB in fp32 with the compressed recipe (the README recipe's Adam
 5e-4 with gamma-0.5 step decays, README.md:75-83).  Ground-truth colours come from closed-form quadrature, i.e. from neither
-the HIP path nor the oracle.  Measured (profiles/r03_psnr_gate_brick.json, 16 live seeds): bf16 +0.064 +- 0.037 dB, bf16_f8
+the HIP path nor the oracle.  Measured (profiles/archive/r03_psnr_gate_brick.json, 16 live seeds): bf16 +0.064 +- 0.037 dB, bf16_f8
 +0.011 +- 0.026 dB relative to fp32.  Without the grain the same geometry with a harsher texture is still climbing at 30.8 dB
 when the recipe ends and a run PAIR differs by +-0.6 dB of trajectory chaos (two fp32 runs that differ in a summation order do
-too): bf16 +0.02 +- 0.21, bf16_f8 -0.18 +- 0.16 dB over 12 seeds (profiles/r03_psnr_gate_brick_no_grain.json) — no detectable
+too): bf16 +0.02 +- 0.21, bf16_f8 -0.18 +- 0.16 dB over 12 seeds (profiles/archive/r03_psnr_gate_brick_no_grain.json) — no detectable
 deficit there either, at five times the noise.
 
 Method: >= 16 LIVE init/jitter seeds (a seed whose fp32 run never leaves the all-white solution — the dead-ReLU density head
 every NeRF implementation knows, identical in all precisions — is replaced, by a criterion on the fp32 run only); per seed the
-fp32-MFMA path (the 1e-4-parity configuration, which tracks the CPU oracle to <= 0.05 dB, profiles/r02_psnr_vs_oracle.json),
+fp32-MFMA path (the 1e-4-parity configuration, which tracks the CPU oracle to <= 0.05 dB, profiles/archive/r02_psnr_vs_oracle.json),
 bf16 and bf16_f8 start from the same weights and consume the same batches and RNG draws; the statistic is the PAIRED difference
 of the mean PSNR over the post-decay checkpoints.  Asserted: |mean difference| <= 0.1 dB with a standard error <= 0.05 dB.
 """

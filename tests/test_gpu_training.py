@@ -116,13 +116,34 @@ def test_fused_training_node_fp32_vs_reference_golden(golden, dev, prefix):
     _check_against_reference_gradients(golden, prefix, ms, loss, res["rgb_fine"])
 
 
+@pytest.mark.parametrize("row_total", ["aten", "exact"])
 @pytest.mark.parametrize("form", ["modular", "fused"])
-def test_training_grads_fp32_all_48_tensors_in_full(golden, golden_grads, dev, form):
+def test_training_grads_fp32_all_48_tensors_in_full(golden, golden_grads, dev, form, row_total):
     """configs[2] shape (gr3: 64 + 128 samples, perturb = 1, noise_std = 0, white background): EVERY one of the 48 gradient tensors
     of the training loss, element for element, against the tensors the reference's own autograd produced
     (tests/golden/reference_golden_grads.npz; 1,191,688 values) — the modular render_rays graph and the fused training node that
     bench.py times.  Bound per tensor: 2e-4 of its max |g| (+ 5e-9: the first-layer biases are cancelling sums of ~6000 terms of
-    1e-6) — the fp32 MFMA path sums the points in another order than ATen's GEMMs, nothing else differs."""
+    1e-6) — the fp32 MFMA path sums the points in another order than ATen's GEMMs, nothing else differs.
+    row_total "exact" (sample_pdf's normaliser correctly rounded instead of in ATen's order): 0.1-0.5 % of the FINE samples land in
+    a neighbouring bin (last-bit knife edges of rendering.py:42), so the fine model's trunk gradients — sums over 6,144 points —
+    move by up to ~1e-2 of their maximum (measured 8.8e-3); the coarse model never sees those samples and keeps the tight bound."""
+    from helpers import fused_draws
+    from nerf_pl_amd import ops
+    from nerf_pl_amd.models.train_step import render_rays_train
+    prev = ops.set_row_total(row_total)
+    try:
+        rows = _gr3_rows(golden, golden_grads, dev, form)
+    finally:
+        ops.set_row_total(prev)
+    print("gr3, %s step, fp32, row total %s: max |g - g_ref| / max |g_ref| per tensor:" % (form, row_total))
+    for row in sorted(rows, key=lambda t: -t[1]):
+        print("   %-28s %.2e  (err %.2e, max|g| %.2e, %d elements)" % row)
+    for name, ratio, err, mx, _ in rows:
+        loose = row_total == "exact" and name.startswith("f.") and not name.startswith(("f.rgb", "f.dir", "f.xyz_encoding_final"))
+        assert err <= (2e-2 if loose else 2e-4) * mx + 5e-9, (form, row_total, name, err, mx)
+
+
+def _gr3_rows(golden, golden_grads, dev, form):
     from helpers import fused_draws
     from nerf_pl_amd.models.train_step import render_rays_train
     params, rays, kw, rng = case_from_golden(golden, None, prefix="gr3")
@@ -135,17 +156,15 @@ def test_training_grads_fp32_all_48_tensors_in_full(golden, golden_grads, dev, f
         res = hip_render(ms, emb, rays, kw, rng, dev)
         loss = torch.nn.functional.mse_loss(res["rgb_coarse"], tgt) + torch.nn.functional.mse_loss(res["rgb_fine"], tgt)
     loss.backward()
-    worst, n_el = 0.0, 0
+    rows, n_el = [], 0
     for tag, m in (("c", ms[0]), ("f", ms[1])):
         for n, prm in m.named_parameters():
             ref = golden_grads[f"gr3_grad_{tag}_{n}"]
             err = (prm.grad.cpu() - ref).abs().max().item()
-            bound = 2e-4 * ref.abs().max().item() + 5e-9
-            worst = max(worst, err / bound)
+            rows.append((tag + "." + n, err / (ref.abs().max().item() + 1e-30), err, ref.abs().max().item(), ref.numel()))
             n_el += ref.numel()
-            assert err <= bound, (form, tag, n, err, ref.abs().max().item())
     assert n_el == 1191688
-    print("gr3, %s step, fp32: worst max-abs error over the 48 gradient tensors = %.3f of the bound (2e-4 max|g| + 5e-9)" % (form, worst))
+    return rows
 
 
 def _check_against_reference_gradients(golden, prefix, ms, loss, rgb_fine):
