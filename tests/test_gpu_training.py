@@ -116,31 +116,66 @@ def test_fused_training_node_fp32_vs_reference_golden(golden, dev, prefix):
     _check_against_reference_gradients(golden, prefix, ms, loss, res["rgb_fine"])
 
 
-@pytest.mark.parametrize("row_total", ["aten", "exact"])
+# tensors of the FINE model upstream of its density head (layers 1-8, sigma): see the docstring below
+def _fine_trunk(name):
+    return name.startswith("f.") and not name.startswith(("f.rgb", "f.dir", "f.xyz_encoding_final"))
+
+
 @pytest.mark.parametrize("form", ["modular", "fused"])
-def test_training_grads_fp32_all_48_tensors_in_full(golden, golden_grads, dev, form, row_total):
+def test_training_grads_fp32_all_48_tensors_in_full(golden, golden_grads, dev, form):
     """configs[2] shape (gr3: 64 + 128 samples, perturb = 1, noise_std = 0, white background): EVERY one of the 48 gradient tensors
     of the training loss, element for element, against the tensors the reference's own autograd produced
     (tests/golden/reference_golden_grads.npz; 1,191,688 values) — the modular render_rays graph and the fused training node that
-    bench.py times.  Bound per tensor: 2e-4 of its max |g| (+ 5e-9: the first-layer biases are cancelling sums of ~6000 terms of
-    1e-6) — the fp32 MFMA path sums the points in another order than ATen's GEMMs, nothing else differs.
-    row_total "exact" (sample_pdf's normaliser correctly rounded instead of in ATen's order): 0.1-0.5 % of the FINE samples land in
-    a neighbouring bin (last-bit knife edges of rendering.py:42), so the fine model's trunk gradients — sums over 6,144 points —
-    move by up to ~1e-2 of their maximum (measured 8.8e-3); the coarse model never sees those samples and keeps the tight bound."""
-    from helpers import fused_draws
-    from nerf_pl_amd import ops
-    from nerf_pl_amd.models.train_step import render_rays_train
-    prev = ops.set_row_total(row_total)
-    try:
-        rows = _gr3_rows(golden, golden_grads, dev, form)
-    finally:
-        ops.set_row_total(prev)
-    print("gr3, %s step, fp32, row total %s: max |g - g_ref| / max |g_ref| per tensor:" % (form, row_total))
+    bench.py times.
+    * the coarse model's 24 tensors and the fine model's colour branch (xyz_encoding_final, dir_encoding, rgb): 2e-4 of the
+      tensor's max |g| (+ 5e-9).  Measured: <= 2e-6 (coarse), <= 5.5e-5 (fine colour branch) — the fp32 MFMA path sums the
+      points in another order than ATen's GEMMs, nothing else differs.
+    * the fine model's trunk and density head (layers 1-8, sigma): 2e-2 of max |g|, measured <= 8.8e-3.  These are not looser
+      kernels, they are a worse-conditioned QUESTION: the fine pass's depths cluster (deltas down to 1e-6), its density
+      gradient is d alpha / d sigma = delta e^(-delta sigma), and delta = z[i+1] - z[i] moves by 0.1-50 % when a depth moves by
+      one ulp.  The depths of the two implementations differ by ulps because the coarse weights do (last bits of an fp32
+      GEMM).  Quantified on the CPU (tests/test_oracle_golden.py::test_fine_pass_conditioning): nudging 30 % of the fine
+      depths of this very case by +-1 ulp moves these tensors of the REFERENCE's arithmetic by up to 1.1e-3 of their maximum,
+      and fp32 against fp64 on IDENTICAL depths by 4.6e-4 (coarse model: 6e-7).  The next test removes the depths from the
+      comparison and holds these tensors to 2e-3."""
+    rows = _gr3_rows(golden, golden_grads, dev, form)
+    print("gr3, %s step, fp32: max |g - g_ref| / max |g_ref| per tensor:" % form)
     for row in sorted(rows, key=lambda t: -t[1]):
         print("   %-28s %.2e  (err %.2e, max|g| %.2e, %d elements)" % row)
     for name, ratio, err, mx, _ in rows:
-        loose = row_total == "exact" and name.startswith("f.") and not name.startswith(("f.rgb", "f.dir", "f.xyz_encoding_final"))
-        assert err <= (2e-2 if loose else 2e-4) * mx + 5e-9, (form, row_total, name, err, mx)
+        assert err <= (2e-2 if _fine_trunk(name) else 2e-4) * mx + 5e-9, (form, name, err, mx)
+
+
+def test_fine_pass_grads_fp32_on_identical_depths(golden, dev):
+    """The fine model's 24 gradient tensors with the depths taken OUT of the comparison: the HIP coarse pass produces z_fine,
+    the HIP fine pass (fused MLP + compositing, autograd through both) and the CPU oracle's fine pass (rendering.py:231-242 on
+    the same rays) both evaluate THOSE depths.  What is left is fp32 arithmetic on identical inputs: every tensor within 2e-3
+    of its max |g| (fp32 against fp64 on identical depths is 4.6e-4 for the reference's own arithmetic on this case)."""
+    from nerf_pl_amd import ops
+    from nerf_pl_amd.models.mlp_autograd import mlp_rays
+    params, rays, kw, rng = case_from_golden(golden, None, prefix="gr3")
+    ms, emb = build_models(params, dev, "fp32")
+    tgt = golden["gr3_target"]
+    rd = rays.to(dev)
+    with torch.no_grad():
+        z = ops.sample_coarse_z(rd, kw["N_samples"], False, 1.0, rng["perturb_rand"].to(dev))
+        raw_c = mlp_rays(ms[0], rd, z)
+        w_c = ops.composite(raw_c, z, rd, None, 0.0, True)[0]
+        zf = ops.fine_z(z, w_c, kw["N_importance"], u=rng["u"].to(dev))
+    raw_f = mlp_rays(ms[1], rd, zf)
+    rgb_f = ops.composite(raw_f, zf, rd, None, 0.0, True)[2]
+    torch.nn.functional.mse_loss(rgb_f, tgt.to(dev)).backward()
+    pf = {k: v.clone().requires_grad_(True) for k, v in params[1].items()}
+    f = O._infer(pf, rays, zf.cpu(), O.posenc(rays[:, 3:6], 4), None, True, False)
+    torch.mean((f["rgb"] - tgt) ** 2).backward()
+    assert (rgb_f.detach().cpu() - f["rgb"].detach()).abs().max().item() <= 1e-5
+    worst = ("", 0.0)
+    for n, prm in ms[1].named_parameters():
+        ref = pf[n].grad
+        ratio = (prm.grad.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, (n, ratio), key=lambda t: t[1])
+        assert ratio <= 2e-3, (n, ratio)
+    print("fine pass on identical depths, fp32: worst max |g - g_oracle| / max |g_oracle| = %.2e (%s)" % (worst[1], worst[0]))
 
 
 def _gr3_rows(golden, golden_grads, dev, form):
