@@ -370,6 +370,65 @@ int nerfhip_train_prologue(const nerfhip_draw* draws_host, int n_draws, const ne
                            const float* const* weights_host, const float* const* biases_host, void* const* packed_host,
                            void* const* packed_bwd_host, int n_models, int dtype, nerfhip_stream_t stream);
 
+/* ---- render_rays in ONE launch  (models/rendering.py:58-244; SURVEY 8b "_render_fwd fused: 32 B in + 40 B out per ray") ----
+ * The whole pipeline of one `render_rays` call — coarse depths (:183-204), coarse MLP over o + d z (:206-217), compositing
+ * (:143-172), sample_pdf + sort (:223-229), fine MLP, compositing — by workgroups that own 4 whole rays each: the MLP runs as
+ * sub-passes of nerfhip_mlp_fwd_rays' own network code, the rays' compositing and fine depths by the same workgroup in between
+ * (same device code, hence the same bits, as nerfhip_mlp_fwd_rays_coarse -> nerfhip_composite_fwd -> nerfhip_fine_z_ex ->
+ * nerfhip_mlp_fwd_rays -> nerfhip_composite_fwd).  The coarse pass always evaluates the full network (`test_time`'s
+ * sigma-only shortcut changes no value: pass rgb_coarse = depth_coarse = NULL to drop what the reference does not return).
+ * The per-point intermediates z_* / raw_* are caller-owned buffers (outputs for whoever wants them; they stay in L2 between the
+ * sub-passes that write and read them).
+ * Shapes the kernels take (nerfhip_render_supported): B % 4 == 0, 4 S_c and 4 (S_c + N_i) multiples of the points per
+ * sub-pass (256 for bf16, 128 for fp32), S_c >= 3; N_i == 0 renders the coarse pass only.  z_* / raw_* / g_raw_* must be
+ * 128-byte aligned (a group's slice of each is then whole cache lines), packed_* 16-byte aligned.                            */
+typedef struct nerfhip_render_args {
+    const float* rays;          /* (B,8) */
+    int64_t B;
+    int S_c, N_i;               /* N_samples, N_importance */
+    const void* packed_coarse;  /* nerfhip_mlp_pack_weights images of the two models (fine unused when N_i == 0) */
+    const void* packed_fine;
+    float* z_coarse;            /* (B,S_c)        out */
+    float* raw_coarse;          /* (B,S_c,4)      out: [r g b sigma] per coarse point */
+    float* z_fine;              /* (B,S_c+N_i)    out */
+    float* raw_fine;            /* (B,S_c+N_i,4)  out */
+    void* save_coarse;          /* training: nerfhip_mlp_act_bytes(B S_c) / (B (S_c+N_i)) bytes of saved activations */
+    void* save_fine;
+    const float* perturb_rand;  /* (B,S_c) uniforms when perturb > 0, else NULL                    rendering.py:203 */
+    float perturb;
+    int use_disp;
+    const float* noise_coarse;  /* (B,S_c) / (B,S_c+N_i) standard-normal draws, read when noise_std != 0      :152 */
+    const float* noise_fine;
+    float noise_std;
+    int white_back;
+    const float* u;             /* (B,N_i) uniforms (row stride u_stride), or NULL = deterministic linspace    :36-39 */
+    int64_t u_stride;
+    float eps;                  /* sample_pdf's eps (1e-5) */
+    int row_total;              /* NERFHIP_ROW_TOTAL_* */
+    float* rgb_coarse;          /* (B,3)  NULL ok */
+    float* depth_coarse;        /* (B)    NULL ok */
+    float* opacity_coarse;      /* (B) */
+    float* rgb_fine;            /* (B,3) (B) (B); unused when N_i == 0 */
+    float* depth_fine;
+    float* opacity_fine;
+    /* training forward only */
+    const float* target;        /* (B,3) */
+    float grad_scale;           /* 2 / (3 B) */
+    float* g_raw_coarse;        /* (B,S_c,4)      out: d loss / d raw */
+    float* g_raw_fine;          /* (B,S_c+N_i,4)  out */
+    float* out3;                /* [loss, psnr, mse] */
+    uint32_t* ticket;           /* one zero-initialised device word owned by the caller; left at zero */
+} nerfhip_render_args;
+/* 1 when the single-launch kernels take this shape and arithmetic (dtype NERFHIP_F32 / NERFHIP_BF16 / NERFHIP_BF16_F8), else 0 */
+int nerfhip_render_supported(int64_t B, int S_c, int N_i, int dtype);
+/* inference: rgb / depth / opacity of both passes (the training-only fields are ignored) */
+int nerfhip_render_fwd(const nerfhip_render_args* args_host, int dtype, nerfhip_stream_t stream);
+/* The forward of a training step (train.py:103-117 up to the loss) in ONE launch: the above with the activations saved for
+ * nerfhip_mlp_bwd_multi, and per pass what nerfhip_composite_train_fine_z / nerfhip_composite_train_loss append to the
+ * quadrature — d MSE / d rgb, the compositing backward (g_raw_*), loss / PSNR / MSE (out3, reduced by the last workgroup to
+ * finish in nerfhip_mse_psnr's own order).  Bit-identical to those launches.                                                 */
+int nerfhip_render_train_fwd(const nerfhip_render_args* args_host, int dtype, nerfhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,9 @@ SIGNATURES = {
                              _c_void_p, _c_void_p],
     "nerfhip_mlp_pack_weights_train_multi": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                              ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
+    "nerfhip_render_supported": [_i64, _int, _int, _int],
+    "nerfhip_render_fwd": [_c_void_p, _int, _c_void_p],                  # (const nerfhip_render_args*: ctypes.addressof(RenderArgs))
+    "nerfhip_render_train_fwd": [_c_void_p, _int, _c_void_p],
     "nerfhip_composite_train": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
                                 _c_void_p, _c_void_p, _c_void_p, _i64, _int, _c_void_p],
     "nerfhip_composite_train_fine_z": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,
@@ -113,6 +116,18 @@ class RayBatch(ctypes.Structure):
     """include/nerfhip.h: nerfhip_ray_batch"""
     _fields_ = [("c2w", _c_void_p), ("rgbs_all", _c_void_p), ("rays", _c_void_p), ("rgbs", _c_void_p), ("H", _int), ("W", _int),
                 ("focal", ctypes.c_double), ("near", _f32), ("far", _f32), ("use_ndc", _int), ("ndc_near_plane", _f32)]
+
+
+class RenderArgs(ctypes.Structure):
+    """include/nerfhip.h: nerfhip_render_args"""
+    _fields_ = [("rays", _c_void_p), ("B", _i64), ("S_c", _int), ("N_i", _int), ("packed_coarse", _c_void_p), ("packed_fine", _c_void_p),
+                ("z_coarse", _c_void_p), ("raw_coarse", _c_void_p), ("z_fine", _c_void_p), ("raw_fine", _c_void_p),
+                ("save_coarse", _c_void_p), ("save_fine", _c_void_p), ("perturb_rand", _c_void_p), ("perturb", _f32), ("use_disp", _int),
+                ("noise_coarse", _c_void_p), ("noise_fine", _c_void_p), ("noise_std", _f32), ("white_back", _int), ("u", _c_void_p),
+                ("u_stride", _i64), ("eps", _f32), ("row_total", _int), ("rgb_coarse", _c_void_p), ("depth_coarse", _c_void_p),
+                ("opacity_coarse", _c_void_p), ("rgb_fine", _c_void_p), ("depth_fine", _c_void_p), ("opacity_fine", _c_void_p),
+                ("target", _c_void_p), ("grad_scale", _f32), ("g_raw_coarse", _c_void_p), ("g_raw_fine", _c_void_p), ("out3", _c_void_p),
+                ("ticket", _c_void_p)]
 
 
 DRAW_UNIFORM, DRAW_NORMAL, DRAW_RANDINT = 0, 1, 2

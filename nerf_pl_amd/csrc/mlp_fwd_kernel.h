@@ -566,21 +566,31 @@ __device__ __forceinline__ void load_slots(const float* __restrict__ row, int h,
 
 constexpr int MODE_EMBEDDED = 0, MODE_RAYS = 1;
 
+// LDS of one workgroup: bias image (one 1 KiB piece per layer, shared by the workgroup) | weight ring | per-wave input-encoding
+// stash (6 slabs: the encodings are needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) /
+// 48 (fp32) registers)
+template <int PREC, bool SAVE> struct FwdLds {
+    static constexpr int kEncStash = (kXyzSlabs + kDirSlabs) * 64 * (int)sizeof(typename PrecTraits<PREC>::Slab);
+    static constexpr int kBiasArea = kNumLayers * kPieceBytes;
+    static constexpr int kRingOff = kBiasArea;
+    static constexpr int kStashOff = kBiasArea + kSlots * kChunkBytes;
+    static constexpr int kBytes = kStashOff + KCfg<PREC, SAVE>::NW * kEncStash;
+};
+
+// The whole network for the 32 * NW points of (virtual) workgroup `blk` — the body of mlp_fwd_kernel, and of every sub-pass of
+// the single-launch render kernels (mlp_render_kernel.h), which call it in a loop with wave-uniform arguments.  On return every
+// wave has issued its output stores (not waited for them); the weight ring / bias image may still be read by slower waves.
 // SV: 0 = inference, 1 = save activations in the compute precision, 2 = save them as block-scaled e4m3 (bf16 compute)
 template <int PREC, int MODE, bool SIGMA_ONLY, int SV>
-__global__ __launch_bounds__((KCfg<PREC, (SV != 0)>::NW * 64), (KCfg<PREC, (SV != 0)>::WPS))
-void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
-                    const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save, FwdZGen zg) {
+__device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned blk, const float* __restrict__ in0,
+                                             const float* __restrict__ in1, int64_t n, int64_t aux, const uint8_t* __restrict__ packed,
+                                             float* __restrict__ out, uint8_t* __restrict__ save, const FwdZGen& zg) {
     using Slab = typename PrecTraits<PREC>::Slab;
     constexpr bool SAVE = SV != 0, F8 = SV == 2;
     constexpr int NW = KCfg<PREC, SAVE>::NW;
     constexpr int NCH = SIGMA_ONLY ? chunks_upto_layer(kSigmaLayer + 1, PREC) : chunks_upto_layer(kNumLayers, PREC);
-    // LDS: bias image (one 1 KiB piece per layer, shared by the workgroup) | weight ring | per-wave input-encoding stash
-    // (6 slabs: the encodings are needed only by layers 0, 4 (xyz) and 10 (dir); parking them in LDS frees 24 (bf16) /
-    // 48 (fp32) registers)
-    constexpr int kEncStash = (kXyzSlabs + kDirSlabs) * 64 * (int)sizeof(Slab);
-    constexpr int kBiasArea = kNumLayers * kPieceBytes;
-    __shared__ __attribute__((aligned(1024))) char lds_all[kBiasArea + kSlots * kChunkBytes + NW * kEncStash];
+    constexpr int kEncStash = FwdLds<PREC, SAVE>::kEncStash;
+    constexpr int kBiasArea = FwdLds<PREC, SAVE>::kBiasArea;
     char* const bias_area = lds_all;
     char* const ring = lds_all + kBiasArea;
     char* const stash_area = ring + kSlots * kChunkBytes;
@@ -597,7 +607,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h = lane >> 5;
-    const int64_t p = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    const int64_t p = (int64_t)blk * (32 * NW) + wave * 32 + (lane & 31);
     const bool valid = p < n;
     const int64_t pc = valid ? p : n - 1;
 
@@ -637,7 +647,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
     st.pending = 0;
     st.pending_prev = 0;
     // wave-uniform base of this wave's activation block (SAVE); the store helpers derive descriptors from it
-    uint8_t* tile_base = SAVE ? save + ((size_t)blockIdx.x * NW + wave) * (F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC))
+    uint8_t* tile_base = SAVE ? save + ((size_t)blk * NW + wave) * (F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC))
                               : (uint8_t*)nullptr;
 
     {
@@ -769,7 +779,7 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
             run_layer_pipe<PREC, NCH, SV, 11, -1, 1, 10>(cx, st, hb, nul, hb, &sigma_p);      // rgb head, accumulator 1
             // (SAVE: output index from a recomputed lane id, otherwise the prologue's 64-bit address stays live across the network)
             const int lane_o = SAVE ? fresh_lane_opaque() : lane;
-            const int64_t po = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + (lane_o & 31);
+            const int64_t po = (int64_t)blk * (32 * NW) + wave * 32 + (lane_o & 31);
             if (po < n && (lane_o >> 5) == 0) {
                 float4 o;
                 o.x = 1.0f / (1.0f + expf(-cx.acc[1][0]));            // sigmoid   nerf.py:79-81
@@ -799,6 +809,14 @@ void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1
             return;
         }
     }
+}
+
+template <int PREC, int MODE, bool SIGMA_ONLY, int SV>
+__global__ __launch_bounds__((KCfg<PREC, (SV != 0)>::NW * 64), (KCfg<PREC, (SV != 0)>::WPS))
+void mlp_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int64_t n, int64_t aux,
+                    const uint8_t* __restrict__ packed, float* __restrict__ out, uint8_t* __restrict__ save, FwdZGen zg) {
+    __shared__ __attribute__((aligned(1024))) char lds_all[FwdLds<PREC, (SV != 0)>::kBytes];
+    mlp_fwd_body<PREC, MODE, SIGMA_ONLY, SV>(lds_all, blockIdx.x, in0, in1, n, aux, packed, out, save, zg);
 }
 
 // ---- one kernel instantiation per translation unit ----------------------------------------------------------------

@@ -14,7 +14,12 @@ import torch
 
 from .. import draws as D
 from .. import ops
-from .mlp_autograd import mlp_rays
+from .mlp_autograd import _needs_grad, mlp_rays
+
+# test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too?  It evaluates
+# the FULL coarse network (same sigma, 21 % more coarse FLOPs = 4 % of the call) and saves four launches per chunk; measured on
+# MI355X (profiles/README.md, round 5) — the setting below is the faster one for 32768-ray chunks.
+FUSE_TEST_TIME = False
 
 __all__ = ['render_rays']
 
@@ -92,6 +97,31 @@ def render_rays(models,
 
         def mlp(model, z, sigma_only):
             return _mlp_points(model, embeddings[0], rays, z, dir_embedded, sigma_only, int(chunk))
+
+    # ---- the whole call in ONE launch (nerfhip_render_fwd) where nothing needs a gradient and the shape fits the kernel's ray
+    # groups: the same four draws in the same order first, then workgroups that own 4 rays each run coarse MLP -> compositing ->
+    # fine depths -> fine MLP -> compositing (csrc/mlp_render_kernel.h; bit-identical to the launches below)
+    if (dev.type == "cuda" and _fusable(models, embeddings) and not (torch.is_grad_enabled() and any(_needs_grad(m) for m in models[:2]))
+            and (N_importance == 0 or models[0].mlp_dtype == models[1].mlp_dtype) and (FUSE_TEST_TIME or not test_time)
+            and ops.render_supported(N_rays, N_samples, N_importance, model_coarse.mlp_dtype)):
+        graph_rng = D.in_graph_stream(dev)
+        rnd = (lambda *sh: D.rand(sh, dev)) if graph_rng else (lambda *sh: torch.rand(*sh, device=dev))
+        rndn = (lambda *sh: D.randn(sh, dev)) if graph_rng else (lambda *sh: torch.randn(*sh, device=dev))
+        perturb_rand = rnd(N_rays, N_samples) if perturb > 0 else None                     # :203
+        noise_c = rndn(N_rays, N_samples)                                                  # :152 (always drawn)
+        u = noise_f = None
+        if N_importance > 0:
+            u = rnd(N_rays, N_importance) if perturb != 0 else None                        # :39
+            noise_f = rndn(N_rays, N_samples + N_importance)                               # :152
+        dtype = model_coarse.mlp_dtype
+        out = ops.render_fwd(rays, N_samples, N_importance, model_coarse.packed_weights(dtype),
+                             models[1].packed_weights(dtype) if N_importance > 0 else None, dtype, use_disp, perturb, perturb_rand,
+                             noise_c, noise_f, noise_std, white_back, u, want_coarse=not test_time)
+        result = {'opacity_coarse': out['opacity_coarse']} if test_time else \
+            {'rgb_coarse': out['rgb_coarse'], 'depth_coarse': out['depth_coarse'], 'opacity_coarse': out['opacity_coarse']}
+        if N_importance > 0:
+            result.update(rgb_fine=out['rgb_fine'], depth_fine=out['depth_fine'], opacity_fine=out['opacity_fine'])
+        return result
 
     # RNG: identical calls, order, shapes and device as the reference.  Inside a hipGraph capture that owns a
     # device-resident generator state (system.GraphedTrainStep: its batch source draws through draws.py) these four come from the

@@ -35,6 +35,26 @@ def fusable(models, embeddings, loss_mod):
             and all(p.requires_grad for m in models for p in m.parameters()))
 
 
+def _forward_launches(models, rays, rgbs, S, N, dtype, use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u, gscale,
+                      packs, acts_c, dev):
+    """The step's forward as four launches (shapes the single-launch kernel does not take; the form it is pinned against)."""
+    z, raw_c = ops.mlp_fwd_rays_coarse(rays, S, packs[0][0], False, dtype, use_disp, perturb, perturb_rand, save=acts_c)  # :189-207
+    if N > 0:
+        _, opac_c, rgb_c, depth_c, g_raw_c, zf = ops.composite_train_fine_z(raw_c, z, rays, noise_c, noise_std, white_back, rgbs,
+                                                                            gscale, N, u=u)                   # :143-172, :223-229
+        acts_f = ops.alloc_acts(zf.numel(), dtype, dev)
+        raw_f = ops.mlp_fwd_rays(rays, zf, packs[1][0], False, dtype, save=acts_f)
+        opac_f, rgb_f, depth_f, g_raw_f, out3 = ops.composite_train_loss(raw_f, zf, rays, noise_f, noise_std, white_back, rgbs,
+                                                                        gscale, rgb_coarse=rgb_c)   # + losses.py:9-14, metrics.py:4-13
+        entries = [(g_raw_f, raw_f, packs[1][1], acts_f), (g_raw_c, raw_c, packs[0][1], acts_c)]   # fine model first (as autograd would)
+        outs = [rgb_c, depth_c, opac_c, rgb_f, depth_f, opac_f]
+    else:
+        opac_c, rgb_c, depth_c, g_raw_c, out3 = ops.composite_train_loss(raw_c, z, rays, noise_c, noise_std, white_back, rgbs, gscale)
+        entries = [(g_raw_c, raw_c, packs[0][1], acts_c)]
+        outs = [rgb_c, depth_c, opac_c]
+    return outs, entries, out3
+
+
 class _TrainRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, rays, rgbs, *params):
@@ -65,20 +85,21 @@ class _TrainRender(torch.autograd.Function):
         # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`
         gscale = float(np.float32(2.0) / np.float32(3 * B))
         acts_c = ops.alloc_acts(B * S, dtype, dev)
-        z, raw_c = ops.mlp_fwd_rays_coarse(rays, S, packs[0][0], False, dtype, use_disp, perturb, perturb_rand, save=acts_c)  # :189-207
-        if N > 0:
-            _, opac_c, rgb_c, depth_c, g_raw_c, zf = ops.composite_train_fine_z(raw_c, z, rays, noise_c, noise_std, white_back, rgbs,
-                                                                                gscale, N, u=u)                   # :143-172, :223-229
-            acts_f = ops.alloc_acts(zf.numel(), dtype, dev)
-            raw_f = ops.mlp_fwd_rays(rays, zf, packs[1][0], False, dtype, save=acts_f)
-            opac_f, rgb_f, depth_f, g_raw_f, out3 = ops.composite_train_loss(raw_f, zf, rays, noise_f, noise_std, white_back, rgbs,
-                                                                            gscale, rgb_coarse=rgb_c)   # + losses.py:9-14, metrics.py:4-13
-            entries = [(g_raw_f, raw_f, packs[1][1], acts_f), (g_raw_c, raw_c, packs[0][1], acts_c)]   # fine model first (as autograd would)
-            outs = [rgb_c, depth_c, opac_c, rgb_f, depth_f, opac_f]
+        if ops.render_supported(B, S, N, dtype):
+            # the whole forward in ONE launch (nerfhip_render_train_fwd, csrc/mlp_render_kernel.h): workgroups that own 4 rays each run
+            # coarse MLP -> compositing + loss gradient + compositing backward + fine depths -> fine MLP -> the same + loss values
+            acts_f = ops.alloc_acts(B * (S + N), dtype, dev) if N > 0 else None
+            o = ops.render_train_fwd(rays, rgbs, gscale, S, N, packs[0][0], packs[1][0] if N > 0 else None, dtype, acts_c, acts_f,
+                                     use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u)
+            out3 = o["out3"]
+            outs = [o["rgb_coarse"], o["depth_coarse"], o["opacity_coarse"]]
+            entries = [(o["g_raw_coarse"], o["raw_coarse"], packs[0][1], acts_c)]
+            if N > 0:
+                outs += [o["rgb_fine"], o["depth_fine"], o["opacity_fine"]]
+                entries.insert(0, (o["g_raw_fine"], o["raw_fine"], packs[1][1], acts_f))    # fine model first (as autograd would)
         else:
-            opac_c, rgb_c, depth_c, g_raw_c, out3 = ops.composite_train_loss(raw_c, z, rays, noise_c, noise_std, white_back, rgbs, gscale)
-            entries = [(g_raw_c, raw_c, packs[0][1], acts_c)]
-            outs = [rgb_c, depth_c, opac_c]
+            outs, entries, out3 = _forward_launches(models, rays, rgbs, S, N, dtype, use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std,
+                                                    white_back, u, gscale, packs, acts_c, dev)
         ctx.models = [models[1], models[0]] if N > 0 else [models[0]]
         ctx.entries, ctx.dtype, ctx.adam = entries, dtype, adam
         ctx.n_params = [len(m.flat_params()) for m in models]

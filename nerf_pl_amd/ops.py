@@ -533,6 +533,113 @@ def mlp_fwd_rays_coarse(rays, n_samples, packed, sigma_only, dtype, use_disp=Fal
     return z, out
 
 
+# ------------------------------------------------------------------------------- render_rays in one launch
+_render_fused = os.environ.get("NERFHIP_RENDER_FUSED", "1") != "0"
+
+
+def set_render_fused(on):
+    """Let render_rays / the fused training node use the single-launch render kernels where they apply (default) or keep them on
+    the multi-launch path (A/B, bit-equality tests).  Returns the previous setting.  NERFHIP_RENDER_FUSED=0 in the environment."""
+    global _render_fused
+    prev, _render_fused = _render_fused, bool(on)
+    return prev
+
+
+def render_supported(B, S_c, N_i, dtype):
+    """True when the single-launch render kernels take this shape (include/nerfhip.h nerfhip_render_supported: B % 4 == 0, 4 S_c and
+    4 (S_c + N_i) multiples of the points per sub-pass) and set_render_fused has not switched them off."""
+    if not _render_fused:
+        return False
+    return bool(_lib.load().nerfhip_render_supported(int(B), int(S_c), int(N_i), mlp_dtype_code(dtype)))
+
+
+def _render_args(rays, S, N, packed_c, packed_f, use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u, eps,
+                 want_coarse):
+    B = rays.shape[0]
+    dev = rays.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    a = _lib.RenderArgs()
+    bufs = {"z_coarse": torch.empty(B, S, **f32), "raw_coarse": torch.empty(B, S, 4, **f32), "opacity_coarse": torch.empty(B, **f32)}
+    if want_coarse:
+        bufs.update(rgb_coarse=torch.empty(B, 3, **f32), depth_coarse=torch.empty(B, **f32))
+    if N > 0:
+        bufs.update(z_fine=torch.empty(B, S + N, **f32), raw_fine=torch.empty(B, S + N, 4, **f32), rgb_fine=torch.empty(B, 3, **f32),
+                    depth_fine=torch.empty(B, **f32), opacity_fine=torch.empty(B, **f32))
+    if perturb > 0:
+        if perturb_rand is None:
+            raise ValueError("perturb>0 needs perturb_rand")
+        perturb_rand = _c(perturb_rand)
+        _check_draw("render", "perturb_rand", perturb_rand, B * S)
+    noise_c = None if noise_std == 0 else (_c(noise_c) if noise_c is not None else None)
+    noise_f = None if (noise_std == 0 or N == 0) else (_c(noise_f) if noise_f is not None else None)
+    if noise_std != 0 and (noise_c is None or (N > 0 and noise_f is None)):
+        raise ValueError("render: noise_std != 0 needs the noise draws")
+    _check_draw("render", "noise_coarse", noise_c, B * S)
+    _check_draw("render", "noise_fine", noise_f, B * (S + N))
+    u_stride = 0
+    if u is not None and N > 0:
+        u = _c(u)
+        u_stride = N if u.dim() == 2 else 0
+        _check_draw("render", "u", u, B * N if u.dim() == 2 else N)
+    else:
+        u = None
+    a.rays, a.B, a.S_c, a.N_i = rays.data_ptr(), B, int(S), int(N)
+    a.packed_coarse = packed_c.data_ptr()
+    a.packed_fine = packed_f.data_ptr() if packed_f is not None else None
+    for k, t in bufs.items():
+        setattr(a, k, t.data_ptr())
+    a.perturb_rand = perturb_rand.data_ptr() if perturb > 0 else None
+    a.perturb, a.use_disp = float(perturb), int(bool(use_disp))
+    a.noise_coarse = noise_c.data_ptr() if noise_c is not None else None
+    a.noise_fine = noise_f.data_ptr() if noise_f is not None else None
+    a.noise_std, a.white_back = float(noise_std), int(bool(white_back))
+    a.u, a.u_stride, a.eps, a.row_total = (u.data_ptr() if u is not None else None), u_stride, float(eps), _row_total
+    keep = (rays, packed_c, packed_f, perturb_rand, noise_c, noise_f, u)
+    return a, bufs, keep
+
+
+@device_guard
+def render_fwd(rays, n_samples, n_importance, packed_coarse, packed_fine, dtype, use_disp=False, perturb=0.0, perturb_rand=None,
+               noise_coarse=None, noise_fine=None, noise_std=0.0, white_back=False, u=None, eps=1e-5, want_coarse=True):
+    """render_rays (rendering.py:58-244) for one ray chunk in ONE launch (nerfhip_render_fwd).  Returns the dict of every buffer
+    the launch wrote: rgb / depth / opacity of both passes (rgb_coarse / depth_coarse only with want_coarse), z_* and raw_*."""
+    require_gpu(rays, perturb_rand, noise_coarse, noise_fine, u)
+    rays = _c(rays)
+    a, bufs, keep = _render_args(rays, n_samples, n_importance, packed_coarse, packed_fine, use_disp, perturb, perturb_rand,
+                                 noise_coarse, noise_fine, noise_std, white_back, u, eps, want_coarse)
+    check(_lib.load().nerfhip_render_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_fwd")
+    return bufs
+
+
+@device_guard
+def render_train_fwd(rays, target, grad_scale, n_samples, n_importance, packed_coarse, packed_fine, dtype, acts_coarse, acts_fine,
+                     use_disp=False, perturb=0.0, perturb_rand=None, noise_coarse=None, noise_fine=None, noise_std=0.0,
+                     white_back=False, u=None, eps=1e-5):
+    """The forward of a training step in ONE launch (nerfhip_render_train_fwd): render_fwd + saved activations + per pass the
+    loss gradient and the compositing backward (g_raw_*) + out3 = [loss, psnr, mse].  Returns the dict of written buffers."""
+    require_gpu(rays, target, perturb_rand, noise_coarse, noise_fine, u)
+    rays, target = _c(rays), _c(target)
+    B, S, N = rays.shape[0], int(n_samples), int(n_importance)
+    if target.numel() != 3 * B or target.dtype != torch.float32:
+        raise ValueError("render_train_fwd: target must be (B,3) fp32")
+    a, bufs, keep = _render_args(rays, S, N, packed_coarse, packed_fine, use_disp, perturb, perturb_rand, noise_coarse, noise_fine,
+                                 noise_std, white_back, u, eps, True)
+    dev = rays.device
+    bufs["g_raw_coarse"] = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+    if N > 0:
+        bufs["g_raw_fine"] = torch.empty(B, S + N, 4, device=dev, dtype=torch.float32)
+    bufs["out3"] = torch.empty(3, device=dev, dtype=torch.float32)
+    a.g_raw_coarse = bufs["g_raw_coarse"].data_ptr()
+    a.g_raw_fine = bufs["g_raw_fine"].data_ptr() if N > 0 else None
+    a.out3 = bufs["out3"].data_ptr()
+    a.save_coarse = acts_coarse.data_ptr()
+    a.save_fine = acts_fine.data_ptr() if N > 0 else None
+    a.target, a.grad_scale = target.data_ptr(), float(grad_scale)
+    a.ticket = _ticket(dev).data_ptr()
+    check(_lib.load().nerfhip_render_train_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_train_fwd")
+    return bufs
+
+
 # ------------------------------------------------------------------------------- MLP backward (K2b)
 @device_guard
 def pack_weights_bwd(weights, dtype, out=None):
