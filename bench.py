@@ -463,6 +463,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         todo.append((name, tag, P, fn, flops, nbytes, what, key_name or name))
 
     keep, entries, dw_b, P_all, chain_b = [], [], 0, 0, 0
+    one_fwd = merged and ops.render_supported(B, S, N, dtype)       # the step's forward is ONE launch (nerfhip_render_train_fwd)
+    fwd_bytes = 0
     for tag, model, zz in (("fine pass", models[1], zf), ("coarse pass", models[0], z)):
         P = zz.numel()
         pk = model.packed_weights(dtype)
@@ -476,8 +478,10 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         gate_b = (P + 31) // 32 * 9 * 1024
         # split-K partials the reduce kernel reads: per split 592 used (out-tile, x-tile) blocks of 4 KiB over the 12 jobs
         ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 12 * 592 * 4096
-        entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
-              FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
+        if not one_fwd:
+            entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
+                  FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
+        fwd_bytes += act_b + 56 * P         # + per point: 16 B raw written and read back twice by the compositing waves, 16 B d loss / d raw, z
         if not merged:
             entry("mlp_bwd_chain_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
@@ -494,6 +498,17 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         keep.append((acts, raw, g_out, ws))
         dw_b += (act_b - gate_b) + dy_b
         P_all += P
+    if one_fwd:
+        tgt_ = torch.rand(B, 3, device=dev)
+        pr_, u_ = torch.rand(B, S, device=dev), torch.rand(B, N, device=dev)
+        gs_ = 2.0 / (3 * B)
+        a_c, a_f = keep[1][0], keep[0][0]
+        pk_c, pk_f = models[0].packed_weights(dtype), models[1].packed_weights(dtype)
+        entry("mlp_render_kernel<train>", "the step's whole forward in ONE launch: coarse + fine MLP, compositing, loss gradient, fine depths, loss",
+              P_all, lambda: ops.render_train_fwd(rays, tgt_, gs_, S, N, pk_c, pk_f, dtype, a_c, a_f, False, 1.0, pr_, None, None, 0.0, True, u_),
+              FLOP_PER_POINT_FULL * P_all, fwd_bytes,
+              "saved activations + gates of both models written once; per point 16 B rgb sigma out and back (L2), 16 B d loss / d raw, depths",
+              key_name="mlp_render_kernel<train>")
     if merged:
         wsm = {}
         ops.mlp_bwd_multi(entries, dtype, workspace=wsm)            # (chains included: fills the dY slabs the dW launch reads)
@@ -510,7 +525,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     # settles at its own shader clock, which on some boxes is LOWER than inside the step's mix of MFMA-bound and HBM-bound kernels
     # (HIP events between the nodes of one graph do not time on this stack: hipErrorInvalidHandle); the six kernels are therefore
     # also replayed TOGETHER, in the step's order, from one graph: `mix_us` = their time per round in the step's own clock mix.
-    order = sorted(range(len(todo)), key=lambda i: (0 if "fwd" in todo[i][0] and "coarse" in todo[i][1] else
+    order = sorted(range(len(todo)), key=lambda i: (0 if ("fwd" in todo[i][0] and "coarse" in todo[i][1]) or "render" in todo[i][0] else
                                                     1 if "fwd" in todo[i][0] else
                                                     2 if "chain" in todo[i][0] and todo[i][1].startswith("fine") else
                                                     3 if "chain" in todo[i][0] else 4 if "dw" in todo[i][0] else 5, i))
@@ -833,8 +848,11 @@ def main():
                        "parallelism": "ray-sharded x%d%s" % (world, ", RCCL grad all-reduce" if dist is not None and a.mode == "train" else ""),
                        "step_form": (None if a.mode != "train" else
                                      "modular autograd graph (render_rays -> MSELoss), separate Adam launch" if a.modular_step else
-                                     "fused node: batch + draws + both weight packs in one launch, coarse depths in the MLP prologue, composite+loss-gradient+"
-                                     "composite-backward (+ fine depths | + loss) per pass, one chain / dW / reduce launch for both models"
+                                     ("fused node: batch + draws + both weight packs in one launch; the whole forward in ONE launch (workgroups own 4 rays: "
+                                      "coarse MLP, compositing + loss gradient + compositing backward + fine depths, fine MLP, the same + loss values); "
+                                      "one chain / dW / reduce launch for both models" if ops.render_supported(B, S, N, a.dtype) else
+                                      "fused node: batch + draws + both weight packs in one launch, coarse depths in the MLP prologue, composite+loss-gradient+"
+                                      "composite-backward (+ fine depths | + loss) per pass, one chain / dW / reduce launch for both models")
                                      + (", Adam applied inside the reduce kernel" if system.fuse_adam else ", separate Adam launch")),
                        "rccl_nranks": rccl_nranks,
                        "capture_fallback": (getattr(state["graphed"], "capture_fallback", None) if a.mode == "train" else None),

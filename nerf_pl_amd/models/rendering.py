@@ -10,6 +10,8 @@ NeRF shape or embedding keeps the same pipeline with the MLP stage unfused (`_ml
 kernel) -> NeRF.forward layer by layer (csrc/linear.hip), in point chunks of `chunk` like the reference's loop
 (rendering.py:115-141).
 """
+import os
+
 import torch
 
 from .. import draws as D
@@ -19,7 +21,7 @@ from .mlp_autograd import _needs_grad, mlp_rays
 # test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too?  It evaluates
 # the FULL coarse network (same sigma, 21 % more coarse FLOPs = 4 % of the call) and saves four launches per chunk; measured on
 # MI355X (profiles/README.md, round 5) — the setting below is the faster one for 32768-ray chunks.
-FUSE_TEST_TIME = False
+FUSE_TEST_TIME = os.environ.get("NERFHIP_FUSE_TEST_TIME", "0") == "1"
 
 __all__ = ['render_rays']
 

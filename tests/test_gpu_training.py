@@ -159,10 +159,10 @@ def test_fine_pass_grads_fp32_on_identical_depths(golden, dev):
     rd = rays.to(dev)
     with torch.no_grad():
         z = ops.sample_coarse_z(rd, kw["N_samples"], False, 1.0, rng["perturb_rand"].to(dev))
-        raw_c = mlp_rays(ms[0], rd, z)
+        raw_c = mlp_rays(ms[0], rd, z, False)
         w_c = ops.composite(raw_c, z, rd, None, 0.0, True)[0]
         zf = ops.fine_z(z, w_c, kw["N_importance"], u=rng["u"].to(dev))
-    raw_f = mlp_rays(ms[1], rd, zf)
+    raw_f = mlp_rays(ms[1], rd, zf, False)
     rgb_f = ops.composite(raw_f, zf, rd, None, 0.0, True)[2]
     torch.nn.functional.mse_loss(rgb_f, tgt.to(dev)).backward()
     pf = {k: v.clone().requires_grad_(True) for k, v in params[1].items()}
