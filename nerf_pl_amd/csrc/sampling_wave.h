@@ -195,7 +195,16 @@ __device__ __forceinline__ void fine_z_wave(float* lds, const float* __restrict_
         if (i < S) out[i + c] = zc_s[i];
         carry = __shfl(c, 63, 64);
     }
-    // new elements: stable rank among the new ones (NaNs are not ordered)
+    // new elements: stable rank among the new ones (NaNs are not ordered).  The inverse cdf is monotone, so with the deterministic
+    // uniforms of a test_time render (rendering.py:36-37, every eval chunk) the new samples arrive already sorted: then the rank
+    // among them IS the index — checked, not assumed (fp32 rounding of the lerp at a bin edge could in principle invert a pair),
+    // and the N^2 / 64 comparisons per lane below (half of this wave's instructions at N = 128) are skipped.
+    bool in_order = true;
+    for (int k = lane; k < N; k += 64) in_order = in_order && (k == 0 || zn_s[k - 1] <= zn_s[k]);
+    if (__all(in_order)) {                  // (wave-uniform)
+        for (int k = lane; k < N; k += 64) out[ub_s[k] + k] = zn_s[k];
+        return;
+    }
     const float4* zn4 = reinterpret_cast<const float4*>(zn_s);
     for (int k = lane; k < N; k += 64) {
         const float x = zn_s[k];
