@@ -319,6 +319,12 @@ def pmc_launch(a):
         for _ in range(2):
             ops.mlp_bwd_multi(entries, a.dtype, workspace=ws)           # chain x 2, merged dW, merged reduce
             ops.mlp_fwd_rays(rays, zf, pk, False, a.dtype)               # the inference forward (north star)
+        if ops.render_supported(B, S, N, a.dtype):                       # the step's forward as ONE launch
+            tgt, pr, u = torch.rand(B, 3, device=dev), torch.rand(B, S, device=dev), torch.rand(B, N, device=dev)
+            pk_c = models[0].packed_weights(a.dtype)
+            for _ in range(2):
+                ops.render_train_fwd(rays, tgt, 2.0 / (3 * B), S, N, pk_c, pk, a.dtype, entries[1][3], entries[0][3], False, 1.0, pr, None, None,
+                                     0.0, True, u)
     torch.cuda.synchronize()
 
 
@@ -382,6 +388,8 @@ def pmc_collect(a, note):
             key, P = "mlp_bwd_dw_kernel<merged>", P_f + P_c
         elif base == "mlp_bwd_reduce_kernel":
             key, P = "mlp_bwd_reduce_kernel<merged>", P_f + P_c
+        elif base == "mlp_render_kernel" and targs and targs[1] != "0":
+            key, P = "mlp_render_kernel<train>", P_f + P_c
         else:
             continue
         db["%s|%s|%d" % (key, a.dtype, P)] = {"hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),

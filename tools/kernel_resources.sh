@@ -29,6 +29,11 @@ for P in 1 0; do for M in 1 0; do for V in 0 1 2 3; do
   EXTRA=""; [ "$V" = 3 ] && EXTRA="-mllvm -amdgpu-sched-strategy=max-memory-clause"
   digest "fwd p$P m$M v$V" -DNH_PREC=$P -DNH_MODE=$M -DNH_VARIANT=$V $EXTRA nerf_pl_amd/csrc/mlp_fwd_variant.hip
 done; done; done
+for P in 1 0; do for SV in 0 1 2; do
+  [ "$P" = 0 ] && [ "$SV" = 2 ] && continue
+  EXTRA=""; [ "$SV" = 2 ] && EXTRA="-mllvm -amdgpu-sched-strategy=max-memory-clause"
+  digest "render p$P sv$SV" -DNH_PREC=$P -DNH_SV=$SV $EXTRA nerf_pl_amd/csrc/mlp_render_variant.hip
+done; done
 digest mlp_bwd_chain -mllvm -amdgpu-sched-strategy=max-memory-clause nerf_pl_amd/csrc/mlp_bwd_chain.hip
 for f in mlp_bwd mlp_dx mlp_pack prologue draws sampling composite posenc loss optim rays linear; do digest $f nerf_pl_amd/csrc/$f.hip; done
 rm -rf $TMP
