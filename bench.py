@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-fuse-adam", action="store_true", help="(the default since round 3; accepted for older command lines)")
     ap.add_argument("--no-extras", action="store_true",
                     help="train mode: skip the side measurements (eval / render / fp8-dW variant / configs[1] and configs[3] steps / PMC passes)")
+    ap.add_argument("--settle", type=int, default=None,
+                    help="untimed replays between the capture and the W warm-up steps (device clocks; default by mode, 0 = none)")
+    ap.add_argument("--series", action="store_true", help="diagnosis: per-step durations of the timed steps (events between the steps) on stderr")
     ap.add_argument("--no-pmc", action="store_true", help="do not take HBM counters in-run (rocprofv3 --pmc passes of this build's kernels)")
     ap.add_argument("--pmc-launch", action="store_true", help=argparse.SUPPRESS)   # child mode of the PMC passes: launch the kernels, print nothing
     ap.add_argument("--force-dist", action="store_true",
@@ -142,9 +145,10 @@ def init_world(a, backend="nccl"):
     return dist, world, rank, local, nranks
 
 
-def timed_region(step_fn, warmup, steps, dist, device):
+def timed_region(step_fn, warmup, steps, dist, device, series=None):
     """The contract's timing: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device synchronize on
-    both sides; the MAX over the ranks is the job's time."""
+    both sides; the MAX over the ranks is the job's time.  `series` (a list, diagnosis only: --series) receives the per-step
+    durations in ms from events recorded between the steps on the current stream."""
     on_gpu = torch.device(device).type == "cuda"
 
     def sync():
@@ -157,11 +161,20 @@ def timed_region(step_fn, warmup, steps, dist, device):
     for _ in range(warmup):
         step_fn()
     sync()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if (series is not None and on_gpu) else None
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
+    if evs is None:
+        for _ in range(steps):
+            step_fn()
+    else:
+        evs[0].record()
+        for i in range(steps):
+            step_fn()
+            evs[i + 1].record()
     sync()
     dt_ = time.perf_counter() - t0
+    if evs is not None:
+        series.extend(round(evs[i].elapsed_time(evs[i + 1]), 4) for i in range(steps))
     if dist is not None:
         t = torch.tensor([dt_], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -682,8 +695,10 @@ def main():
 
     step = train_step if a.mode == "train" else (eval_step if a.mode == "eval" else render_step)
 
+    series = [] if a.series else None
+
     def timed(step_fn, warmup, steps):
-        return timed_region(step_fn, warmup, steps, dist, dev)
+        return timed_region(step_fn, warmup, steps, dist, dev, series=series)
 
     def side_steps():
         """Extras of the default line, measured AFTER the headline's timed region: the fp8-dW variant of the same step (its own
@@ -730,7 +745,29 @@ def main():
         del sys3, opt3, st3
         return ex
 
-    dt = timed(step, max(a.warmup, 5) if a.mode == "train" else a.warmup, a.steps)     # >= 5: 3 eager + capture + 1 replay
+    # Setup, before the contract's W untimed + K timed steps:
+    #  (i)  the step is BUILT: the stepper's 3 eager steps (autograd state, allocations) and the capture of its hipGraph.  Until
+    #       round 4 these four calls were counted as the first four of the W warm-up steps (W = 5 left one replay);
+    #  (ii) the device is brought to its SUSTAINED state: right after the capture the first ~60 replays run 5-15 % slower than the
+    #       ones after them (profiles/r05_replay_series.txt: 1.28-1.33 ms for replays 1-5, 1.20 for 6-15, 1.13-1.14 from ~70 on;
+    #       the host-bound eager steps leave the GPU mostly idle and its clocks low).  A training run is 10^5 such steps, so the
+    #       metric is the sustained rate; the first K replays after the capture are timed too and reported beside it
+    #       (`cold_start_ms_per_step`), then --settle replays run untimed (default: by mode; 0 = none).
+    # Every rank runs the same counts (the collectives of an N > 1 step stay matched).
+    cold_ms = None
+    settle = a.settle if a.settle is not None else {"train": 150, "render": 300, "eval": 1}[a.mode]
+    if a.mode == "train" and not a.no_graph:
+        for _ in range(4):                                   # 3 eager steps + capture (and its first replay)
+            step()
+    if settle > 0:
+        k_cold = min(a.steps, settle)
+        cold_ms = timed_region(step, 0, k_cold, dist, dev) / k_cold * 1e3
+        for _ in range(settle - k_cold):
+            step()
+    dt = timed(step, a.warmup, a.steps)
+    if series is not None and rank == 0:
+        print("[bench] per-step ms of the timed steps: %s" % json.dumps(series), file=sys.stderr, flush=True)
+        series = None
 
     if rank == 0:
         extra = {}
@@ -870,6 +907,13 @@ def main():
                                       "two hipGraphs (fwd+bwd | Adam), flat-buffer all-reduces issued eagerly in between"
                                       if state["graphed"] is not None else "eager, hook-overlapped all-reduces"))},
         }
+        out["setup"] = {"build_calls_before_warmup": 4 if (a.mode == "train" and not a.no_graph) else 0,
+                        "settle_replays_before_warmup": settle,
+                        "note": "outside W + K: 3 eager steps + hipGraph capture, then `settle_replays` untimed replays (the first ~60 "
+                                "replays after a cold start run 5-15 % slower: device clocks); the first K of them are timed as "
+                                "cold_start_ms_per_step; --settle 0 measures right after the capture"}
+        if cold_ms is not None:
+            out["cold_start_ms_per_step"] = round(cold_ms, 4)
         out.update(extra)
         if not a.no_cpu_baseline and world == 1:                # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(B, S, N, a.cpu_seconds, a.mode == "train")
