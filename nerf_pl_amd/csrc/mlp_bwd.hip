@@ -252,7 +252,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         constexpr int NXT = decltype(nxt_c)::value, NSL = decltype(nsl_c)::value;
         // class (8, 34) = the final layer with the sigma head folded in: stage = [dY_feat 16][h8 16][dY_sigma 2] slabs; every wave
         // adds ONE MFMA per k-step, dY_sigma x (X tile `wave`), into an accumulator of its own
-        constexpr bool FOLD = (PREC == NERFHIP_BF16) && NXT == 8 && NSL == 34;
+        constexpr bool FOLD = NXT == 8 && NSL == 34;               // (bf16 since round 4, fp32 since round 5)
         constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
         constexpr int LPW = (NP + 7) / 8;
         constexpr int D = dw_depth<PREC>(NP);
@@ -415,6 +415,12 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                             const float b = *reinterpret_cast<const float*>(x_base + 2 * x * SLAB_BYTES + f32_off + pt * 32);
                             acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x], 0, 0, 0);
                         }
+                        if constexpr (FOLD) {                          // dY_sigma (slabs 32, 33 of the stage) x X tile `wave`
+                            const float as = *reinterpret_cast<const float*>(st_base + 32 * SLAB_BYTES + f32_off + pt * 32);
+                            const float bs = *reinterpret_cast<const float*>(x_base + 2 * wave * SLAB_BYTES + f32_off + pt * 32);
+                            dbacc_sig += as;
+                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc_sig, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -449,8 +455,8 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         case 2: run(integral_constant<int, 2>{}, integral_constant<int, 20>{}); break;                 // first layer: 16 + 4
         case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}); break;                 // rgb head: 2 + 8
         case 8:
-            if (PREC == NERFHIP_BF16 && jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
-                run(integral_constant<int, 8>{}, integral_constant<int, (PREC == NERFHIP_BF16 ? 34 : 32)>{});   // final layer + folded sigma head: 16 + 16 + 2
+            if (jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
+                run(integral_constant<int, 8>{}, integral_constant<int, 34>{});                        // final layer + folded sigma head: 16 + 16 + 2
             else if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
             else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head: 2 + 16
             break;
@@ -540,7 +546,10 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     const uint8_t* __restrict__ dys_base = jobs.dys[jid];
     const int dyp = jb.dy_slabs / 2, x1p = jb.x1_slabs / 2, x2p = jb.x2_slabs / 2;
     const int n_ot = dyp, n_xt = x1p + x2p;
-    const int np = dyp + n_xt;                                 // pieces per tile
+    // the final layer's workgroups also form the sigma head's gradient (same X: h8 read once; see mlp_bwd_dw_kernel): their tile
+    // carries the dY_sigma pair as its LAST piece and the section's scale in slot 3 of the wave's scale dwords
+    const bool fold = jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid;
+    const int np = dyp + n_xt + (fold ? 1 : 0);                // pieces per tile
     const int dy_pair0 = jb.dy_off / 2, x1_pair0 = jb.x1_off / 2, x2_pair0 = jb.x2_off / 2;
     // tile PAIRS per split (K = 64 points per MFMA); ntiles is a multiple of 8
     const int64_t npairs = ntiles / 2;
@@ -555,37 +564,50 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // scale DMA: lane i < 32 -> (tile i >> 4, slot i & 15) lands at dword i of the wave's scale area: slot 0 = the dY
     // section's scale, slot 1 = the x1 section's, slots >= 2 = the x2 section's (x1's when there is no x2)
     const int s_tile = (lane >> 4) & 1, s_slot = lane & 15;
-    const int s_from_dy = s_slot == 0;
-    const int s_pos = s_from_dy ? f8_dy_section(jb.dy_off)
-                                : ((s_slot == 1 || x2p == 0) ? f8_x_section(jb.x1_off) : f8_x_section(jb.x2_off));
+    const bool s_sigma = fold && s_slot == 3;
+    const int s_from_dy = s_slot == 0 || s_sigma;
+    const int s_pos = s_sigma ? f8_dy_section(kDySigma)
+                              : (s_slot == 0 ? f8_dy_section(jb.dy_off)
+                                             : ((s_slot == 1 || x2p == 0) ? f8_x_section(jb.x1_off) : f8_x_section(jb.x2_off)));
+    // which piece of a tile pair each of this wave's LPW DMAs fetches does not depend on the stage: (dY or X block, byte offset from
+    // the pair's first tile block, LDS offset in the stage) once, ahead of the loop (wave-uniform; the stage loop only adds the pair's
+    // two block pointers — the selection used to be a branch ladder per DMA)
+    bool p_dy[LPW];
+    unsigned p_off[LPW], p_dst[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int pi = wave + 8 * i;
+        if (pi >= 2 * np) pi = 2 * np - 1;                                           // duplicate DMA of the last piece
+        const int tl = pi >= np ? 1 : 0, pp = pi - tl * np;
+        int pair;
+        if (pp < dyp) { p_dy[i] = true; pair = dy_pair0 + pp; }
+        else if (fold && pp == np - 1) { p_dy[i] = true; pair = kDySigma / 2; }
+        else if (pp < dyp + x1p) { p_dy[i] = false; pair = x1_pair0 + pp - dyp; }
+        else { p_dy[i] = false; pair = x2_pair0 + pp - dyp - x1p; }
+        p_off[i] = (unsigned)(pair * kPieceBytes + tl * (p_dy[i] ? f8_dy_tile_bytes() : f8_act_tile_bytes()));
+        p_dst[i] = (unsigned)(pi * kPieceBytes);
+    }
     auto issue_stage = [&](int64_t it) {
         int64_t P = p_first + (it < my_pairs ? it : my_pairs - 1);                   // past the end: re-fetch the last pair
         if (P >= npairs) P = npairs - 1;
         const unsigned slot = lds_base + (unsigned)((it % DEPTH) * STAGE_BYTES);
+        const uint8_t* dyb = dys_base + (size_t)(2 * P) * f8_dy_tile_bytes();
+        const uint8_t* acb = acts_base + (size_t)(2 * P) * f8_act_tile_bytes();
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            int pi = wave + 8 * i;
-            if (pi >= 2 * np) pi = 2 * np - 1;                                       // duplicate DMA of the last piece
-            const int tl = pi >= np ? 1 : 0, pp = pi - tl * np;
-            const int64_t T = 2 * P + tl;
-            const uint8_t* src;
-            if (pp < dyp) src = dys_base + (size_t)T * f8_dy_tile_bytes() + (size_t)(dy_pair0 + pp) * kPieceBytes;
-            else if (pp < dyp + x1p) src = acts_base + (size_t)T * f8_act_tile_bytes() + (size_t)(x1_pair0 + pp - dyp) * kPieceBytes;
-            else src = acts_base + (size_t)T * f8_act_tile_bytes() + (size_t)(x2_pair0 + pp - dyp - x1p) * kPieceBytes;
-            glds16b_nt(src + dma_unit * 16, slot + (unsigned)(pi * kPieceBytes));
-        }
+        for (int i = 0; i < LPW; ++i)
+            glds16b_nt((p_dy[i] ? dyb : acb) + p_off[i] + dma_unit * 16, slot + p_dst[i]);
         {
-            const int64_t T = 2 * P + s_tile;
-            const uint8_t* src = s_from_dy ? dys_base + (size_t)T * f8_dy_tile_bytes() + f8_dy_scale_off()
-                                           : acts_base + (size_t)T * f8_act_tile_bytes() + f8_act_scale_off();
+            const uint8_t* src = s_from_dy ? dyb + (size_t)s_tile * f8_dy_tile_bytes() + f8_dy_scale_off()
+                                           : acb + (size_t)s_tile * f8_act_tile_bytes() + f8_act_scale_off();
             glds4b(src + 4 * s_pos, lds_scales + (unsigned)(((it % DEPTH) * 8 + wave) * SCALE_BYTES));
         }
     };
 
     f32x16 acc[kDwMaxXTiles];
     f32x16 accb;
+    f32x16 acc_sig, accb_sig;                                  // (folded sigma head)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) accb[r] = acc_sig[r] = accb_sig[r] = 0.0f;
 #pragma unroll
     for (int x = 0; x < kDwMaxXTiles; ++x)
 #pragma unroll
@@ -612,8 +634,9 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // and the compiler schedules across tiles.  (With the runtime guard `if (x < n_xt)` every tile was a branch target of its own:
     // 4 ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, ten times per iteration in the same registers — the kernel was bound by ten
     // exposed LDS round trips per ring stage, not by HBM: "a workgroup's time follows its iteration count, not its bytes".)
-    auto run = [&](auto nxt_c) {
+    auto run = [&](auto nxt_c, auto fold_c) {
         constexpr int NXT = decltype(nxt_c)::value;
+        constexpr bool FOLD = decltype(fold_c)::value;
         for (int64_t it = 0; it < my_pairs; ++it) {
             // stage `it` landed (DEPTH-2 younger stages of LPW + 1 DMAs may still fly), everyone done with stage it-1
 #if NERFHIP_DW_PROBE
@@ -653,12 +676,24 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                 const i32x8 a = load_frag(st_base + wave * kPieceBytes);
                 const int sa = *reinterpret_cast<const int*>(sc_base);
                 const int sx1 = *reinterpret_cast<const int*>(sc_base + 4), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
+                [[maybe_unused]] i32x8 a_sg, b_sg;
+                [[maybe_unused]] int sa_sg = 0;
+                if constexpr (FOLD) {                                   // dY_sigma pair (the tile's last piece) and X tile `wave`
+                    a_sg = load_frag(st_base + (np - 1) * kPieceBytes);
+                    b_sg = load_frag(x_base + wave * kPieceBytes);
+                    sa_sg = *reinterpret_cast<const int*>(sc_base + 12);
+                }
                 i32x8 b[RD];
                 b[0] = load_frag(x_base);
                 if (NXT > 1) b[1] = load_frag(x_base + kPieceBytes);
                 __builtin_amdgcn_sched_barrier(0);
                 accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, 127);   // bias: dY x 1.0
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FOLD) {
+                    acc_sig = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, b_sg, acc_sig, NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, sx1);
+                    accb_sig = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, ones, accb_sig, NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, 127);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int x = 0; x < NXT; ++x) {
                     if (x + 2 < NXT) b[(x + 2) % RD] = load_frag(x_base + (x + 2) * kPieceBytes);
@@ -674,11 +709,14 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         }
     };
     switch (n_xt) {
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 8: run(std::integral_constant<int, 8>{}); break;
-        case 9: run(std::integral_constant<int, 9>{}); break;
-        default: run(std::integral_constant<int, 10>{}); break;          // 10 = kDwMaxXTiles (the skip layer)
+        case 2: run(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 4: run(std::integral_constant<int, 4>{}, std::false_type{}); break;
+        case 8:
+            if (fold) run(std::integral_constant<int, 8>{}, std::true_type{});       // final layer + folded sigma head
+            else run(std::integral_constant<int, 8>{}, std::false_type{});
+            break;
+        case 9: run(std::integral_constant<int, 9>{}, std::false_type{}); break;
+        default: run(std::integral_constant<int, 10>{}, std::false_type{}); break;          // 10 = kDwMaxXTiles (the skip layer)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
 
@@ -698,6 +736,17 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             float* bdst = slb + 8 * kDwMaxXTiles * 64 * 16 + wave * 64;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
+        }
+        if (fold) {                              // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
+            float* dst = slb + ((size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 64 + lane) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                reinterpret_cast<float4*>(dst)[q] = make_float4(acc_sig[4 * q], acc_sig[4 * q + 1], acc_sig[4 * q + 2], acc_sig[4 * q + 3]);
+            if (wave == 0 && (lane & 31) == 0) {
+                float* bdst = slb + (size_t)kDwFoldBiasCol * 64 * 16;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb_sig[rr];
+            }
         }
     }
 #if NERFHIP_DW_PROBE
@@ -869,7 +918,7 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 #define NERFHIP_DW_COST_B 35
 #endif
 #ifndef NERFHIP_DW_FOLD_SIGMA
-#define NERFHIP_DW_FOLD_SIGMA 1      // bf16: the final layer's workgroups also form the sigma head's gradient (same X: h8 read once)
+#define NERFHIP_DW_FOLD_SIGMA 1      // the final layer's workgroups also form the sigma head's gradient (same X: h8 read once)
 #endif
 #ifndef NERFHIP_DW_MIN_ITERS
 #define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
@@ -901,7 +950,7 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         // launch has not been re-measured.  NERFHIP_DW_COST_A / _B = a + b x KiB instead, for experiments)
         const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
         const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
-        const bool fold = dtype == NERFHIP_BF16 && NERFHIP_DW_FOLD_SIGMA;
+        const bool fold = NERFHIP_DW_FOLD_SIGMA;             // (bf16 since round 4; e4m3 and fp32 since round 5)
         cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs + (fold && j % kNumDwJobs == kDwJobFinal ? 2 : 0));
         if (cost[j] < 1) cost[j] = 1;
         units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
