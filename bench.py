@@ -445,6 +445,14 @@ def event_time(fn, reps, warm=3, graph=False):
             for _ in range(reps):
                 fn()
         g.replay()
+        # same settle as the headline's (main(): the first replays after idle run at ramping clocks): replay for ~60 ms before timing
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        for _ in range(min(200, int(60.0 / max(e0.elapsed_time(e1), 0.05)))):
+            g.replay()
         us = []
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(512, 2)
 void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     constexpr int SPP = DwTraits<PREC>::SPP;
     constexpr int SLAB_BYTES = SPP * kPieceBytes;
+    constexpr int IL = act_il(PREC);
     // The ring is sized in BYTES, not stages (round 4): a stage of a job is its own (dY + X slabs) KiB, and the ring holds as many
     // of them as fit — bf16: 4 for the skip layer (36 KiB), 5 for the 256 x 256 layers, 6 / 8 / 8 / 12 for the dir / first / sigma /
     // rgb jobs.  Job class = (X tiles, slabs per stage): the iteration loop exists once per class, so the stage count, the DMAs
@@ -270,8 +271,8 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         auto next_stage = [&](int64_t it) {
             int64_t T = t_first + (it < my_tiles ? it : my_tiles - 1) * (NERFHIP_DW_BLOCKED ? 1 : nsplit);   // past the end: re-fetch
             if (T >= ntiles) T = ntiles - 1;
-            abase = acts_base + (size_t)T * act_tile_bytes(PREC);
-            dbase = dys_base + (size_t)T * kDySlabs * 64 * (16 * SPP);
+            abase = acts_base + tile_block_off(T, act_tile_bytes(PREC), IL);      // (bf16: the block's pieces are IL KiB apart, mlp_layout.h)
+            dbase = dys_base + tile_block_off(T, kDySlabs * 64 * (16 * SPP), IL);
             slot = lds_base + (unsigned)(s_issue * STAGE);
             s_issue = (s_issue + 1 == D) ? 0 : s_issue + 1;
         };
@@ -290,10 +291,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             if (pi >= NP) pi = NP - 1;                                          // (classes without sharing) duplicate DMA of the last piece
             const int sl = pi / SPP, sub = pi % SPP;
             const uint8_t* src;
-            if (FOLD && sl >= 32) src = dbase + (size_t)(kDySigma + sl - 32) * 64 * (16 * SPP);
-            else if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP);
-            else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP);
-            else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP);
+            if (FOLD && sl >= 32) src = dbase + (size_t)(kDySigma + sl - 32) * 64 * (16 * SPP) * IL;
+            else if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP) * IL;
+            else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP) * IL;
+            else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP) * IL;
             // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
             // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
             const uint8_t* g = src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even);

@@ -162,7 +162,7 @@ template <int PREC, typename Slab>
 __device__ __forceinline__ void store_slab(BwdStream<PREC>& st, __amdgpu_buffer_rsrc_t rsrc, int sec, const Slab& s, int lane) {
     const u32x4* src = reinterpret_cast<const u32x4*>(&s);
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
-    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab));
+    const unsigned soff = (unsigned)(sec * 64 * sizeof(Slab) * act_il(PREC));        // (slab modes only: pieces IL KiB apart, mlp_layout.h)
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
         // soffset must stay 0 (offset folded into VOFFSET): gfx950 store-data hazard, see mlp_fwd.hip save_slabs
@@ -238,7 +238,7 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
     };
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
-        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)(gate_off + mask_piece * kPieceBytes), 0);
+        gates = __builtin_amdgcn_raw_buffer_load_b128(acts, (unsigned)lane * 16u, (unsigned)((gate_off + mask_piece * kPieceBytes) * act_il(PREC, F8)), 0);
     float mx = 0.0f;
     f32x16 acc2[2];
     // compile-time loop over the tiles: guarantees static register indexing of the slab arrays (a `#pragma unroll` loop of
@@ -348,8 +348,8 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
         if constexpr (!F8) {
             // per-layer descriptor: the (possibly runtime, wave-uniform) section offset sits in its SALU-computed base, the
             // per-tile offsets are immediates (soffset stays 0: gfx950 store-data hazard, see store_slab)
-            __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab), 0,
-                                                                              (int)(2 * NT * 64 * sizeof(Slab)), 0x00020000);
+            __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab) * act_il(PREC), 0,
+                                                                              (int)(2 * NT * 64 * sizeof(Slab) * act_il(PREC)), 0x00020000);
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) store_slab(st, dys_l, 2 * t + sl, out[2 * t + sl], lane);
         }
@@ -401,10 +401,15 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
         g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
     }
 
+    constexpr int IL = act_il(PREC, F8);     // the saved blocks' pieces are IL KiB apart (mlp_layout.h: bf16 slabs 8, otherwise 1)
     __amdgpu_buffer_rsrc_t acts = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(acts_base) + (size_t)tile * kActTile, 0, kActTile, 0x00020000);
-    uint8_t* dy_tile = dys_base + (size_t)tile * kDyTile;
-    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(dy_tile, 0, kDyTile, 0x00020000);
+        const_cast<uint8_t*>(acts_base) + tile_block_off(tile, kActTile, IL), 0, kActTile * IL, 0x00020000);
+#ifdef NERFHIP_EXP_TILEWRAP    // timing experiment only (results invalid): every wave stores into one of a few L2-resident tile blocks
+    uint8_t* dy_tile = dys_base + tile_block_off(tile & (NERFHIP_EXP_TILEWRAP - 1), kDyTile, IL);
+#else
+    uint8_t* dy_tile = dys_base + tile_block_off(tile, kDyTile, IL);
+#endif
+    __amdgpu_buffer_rsrc_t dys = __builtin_amdgcn_make_buffer_rsrc(dy_tile, 0, kDyTile * IL, 0x00020000);
 
 
     BwdStream<PREC> st;

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void mlp_dx_embedded_kernel(const uint8_t* __r
     if (tile >= ntiles) return;
     const int h = lane >> 5;
     const int64_t p = tile * 32 + (lane & 31);
-    const uint8_t* tb = dys + (size_t)tile * kDySlabs * 64 * sizeof(Slab);
-    auto slab = [&](int sec) { return *reinterpret_cast<const Slab*>(tb + ((size_t)sec * 64 + lane) * sizeof(Slab)); };
+    constexpr int IL = act_il(PREC);          // bf16 slabs: the block's pieces are IL KiB apart (mlp_layout.h)
+    const uint8_t* tb = dys + tile_block_off(tile, kDySlabs * 64 * (int)sizeof(Slab), IL);
+    auto slab = [&](int sec) { return *reinterpret_cast<const Slab*>(tb + ((size_t)sec * 64 * IL + lane) * sizeof(Slab)); };
 
     float ax[kXyzCh];
 #pragma unroll

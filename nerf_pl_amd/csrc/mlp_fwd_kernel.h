@@ -209,19 +209,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int PREC, int NCH, typename Slab, bool CS>
 __device__ __forceinline__ void save_slabs(WeightStream<PREC, NCH, CS>& st, uint8_t* tile_ptr, int sec,
                                            const Slab* slabs, int n, int lane) {
+    constexpr int IL = act_il(PREC);        // (non-F8 callers only) piece pitch of the interleaved block, mlp_layout.h
     // One descriptor per call with the section offset folded into its (wave-uniform, SALU-computed) base: every store
     // then uses the SAME voffset VGPR (lane * sizeof(Slab)) and a small immediate.  (Folding the section offset into
     // the voffset instead made hipcc hoist ~40 distinct per-lane offset VGPRs to the top of the kernel: +80 live
     // registers, spills.)
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + (size_t)sec * 64 * sizeof(Slab), 0,
-                                                                  (int)(n * 64 * sizeof(Slab)), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ptr + (size_t)sec * 64 * sizeof(Slab) * IL, 0,
+                                                                  (int)(n * 64 * sizeof(Slab) * IL), 0x00020000);
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(Slab);
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         const u32x4* src = reinterpret_cast<const u32x4*>(&slabs[i]);
 #pragma unroll
         for (int q = 0; q < (int)(sizeof(Slab) / 16); ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(src[q], rs, voff + (unsigned)(i * 64 * sizeof(Slab)) + 16 * q, 0, NERFHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(src[q], rs, voff + (unsigned)(i * 64 * sizeof(Slab) * IL) + 16 * q, 0, NERFHIP_STORE_AUX);
             st.pending += 1;
         }
     }
@@ -360,7 +361,7 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
         const int lane = fresh_lane();
         if (!F8 && (p & 3) == 3) save_slabs(st, cx.tile, layer_out_sec(PL) + 2 * pt + (p >> 2), &o, 1, lane);
         if (RELU && p == 7 && (pt & 1)) {
-            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(cx.gate_base + layer_gate_piece(PL) * kPieceBytes, 0,
+            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(cx.gate_base + layer_gate_piece(PL) * kPieceBytes * act_il(PREC, F8), 0,
                                                                            kPieceBytes, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(gw, grs, (unsigned)lane * 16u + 4u * (unsigned)(pt >> 1), 0, 0);
             st.pending += 1;
@@ -647,8 +648,15 @@ __device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned
     st.pending = 0;
     st.pending_prev = 0;
     // wave-uniform base of this wave's activation block (SAVE); the store helpers derive descriptors from it
-    uint8_t* tile_base = SAVE ? save + ((size_t)blk * NW + wave) * (F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC))
+    constexpr int IL = act_il(PREC, F8);    // the saved block's pieces are IL KiB apart (mlp_layout.h: bf16 slabs 8, otherwise 1)
+#ifdef NERFHIP_EXP_TILEWRAP    // timing experiment only (results invalid): every wave stores into one of a few L2-resident tile blocks
+    uint8_t* tile_base = SAVE ? save + tile_block_off((long long)(((size_t)blk * NW + wave) & (NERFHIP_EXP_TILEWRAP - 1)),
+                                                      F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC), IL)
                               : (uint8_t*)nullptr;
+#else
+    uint8_t* tile_base = SAVE ? save + tile_block_off((long long)blk * NW + wave, F8 ? f8_act_tile_bytes() : act_tile_bytes(PREC), IL)
+                              : (uint8_t*)nullptr;
+#endif
 
     {
         // bias image: the bias piece of every layer this kernel runs, DMA'd once from the stream's bias block (older than
@@ -711,7 +719,7 @@ __device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned
         cx.smem_lane = smem_lane;
         cx.enc_x = enc_x + lane * (int)sizeof(Slab);
         cx.enc_d = enc_d + lane * (int)sizeof(Slab);
-        uint8_t* const gate0 = SAVE ? tile_base + (F8 ? f8_act_gate_off() : act_mask_off(PREC)) : (uint8_t*)nullptr;
+        uint8_t* const gate0 = SAVE ? tile_base + (F8 ? f8_act_gate_off() : act_mask_off(PREC) * IL) : (uint8_t*)nullptr;
         uint8_t* const scale0 = F8 ? tile_base + f8_act_scale_off() : (uint8_t*)nullptr;
         const char* const bias0 = bias_area + h * 16;
         cx.tile = tile_base;
@@ -754,8 +762,8 @@ __device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned
                 st.gsrc = gsrc0 + (size_t)loop_chunk_shift(PREC) * kChunkBytes;
                 cx.bias_lane = bias0 + kDL * kPieceBytes;
                 if constexpr (SAVE) {
-                    cx.tile = tile_base + (F8 ? 8 * kDL * kPieceBytes : 16 * kDL * 64 * (int)sizeof(Slab));
-                    cx.gate_base = gate0 + kDL * kPieceBytes;
+                    cx.tile = tile_base + (F8 ? 8 * kDL * kPieceBytes : 16 * kDL * 64 * (int)sizeof(Slab) * IL);
+                    cx.gate_base = gate0 + kDL * kPieceBytes * IL;
                 }
                 if constexpr (F8) cx.scale_base = scale0 + kDL * 4;
             }

@@ -188,6 +188,25 @@ NH_HD constexpr int slab_bytes(int prec) { return prec == 0 /*NERFHIP_F32*/ ? 32
 NH_HD constexpr int act_mask_off(int prec) { return kActSlabs * slab_bytes(prec); }
 NH_HD constexpr int act_tile_bytes(int prec) { return act_mask_off(prec) + kMaskPieces * kPieceBytes; }
 
+// Optional interleave of the saved-tensor blocks (bf16 slabs; round 5 experiment, OFF by default).  A wave tile's block (activations:
+// 158 slabs + 9 gate pieces; dY: 156 slabs) is one contiguous run of 1 KiB pieces.  The 8 waves of a workgroup store their slab s at
+// the same time, 8 pieces that lie 156-167 KiB apart; with NERFHIP_ACT_IL = 8 the blocks of 8 consecutive tiles (one workgroup's) are
+// interleaved piece by piece,
+//     piece p of tile t  ->  byte ((t / IL) * IL * pieces_per_tile + p * IL + t % IL) * 1 KiB,
+// so that they form ONE 8 KiB run.  A pure-store kernel of the chain's shape streams 5.67 TB/s in that layout against 5.10 TB/s
+// tile-major (tools/probes/write_layout.hip), but the real kernels do not notice: same-box A/B of the whole step 1.0621 / 1.0674 /
+// 1.0627 ms interleaved against 1.0636 / 1.0666 / 1.0654 ms tile-major, chain 279-286 us either way (profiles/r05_ab_interleave.txt;
+// all 111 GPU tests of the paths that write or read the blocks pass with IL = 8).  Every producer and consumer addresses the blocks
+// through act_il() / tile_block_off(), so the switch stays as a build flag.  fp32 slabs and the e4m3 pair pieces are always IL = 1.
+#ifndef NERFHIP_ACT_IL
+#define NERFHIP_ACT_IL 1
+#endif
+NH_HD constexpr int act_il(int prec, bool f8 = false) { return (prec == 1 /*NERFHIP_BF16*/ && !f8) ? NERFHIP_ACT_IL : 1; }
+// byte offset of piece 0 of wave tile `tile` in a buffer of blocks of `tile_bytes`; its piece p follows at p * il KiB
+NH_HD inline size_t tile_block_off(long long tile, int tile_bytes, int il) {
+    return (size_t)(tile / il) * (size_t)il * (size_t)tile_bytes + (size_t)(tile % il) * kPieceBytes;
+}
+
 // Backward chain writes dL/d(pre-activation) slabs in the same format.
 constexpr int kDyRgb = 0;                   // 2 slabs (3 real features, rest zero)
 constexpr int kDyDir = 2;                   // 8 slabs
