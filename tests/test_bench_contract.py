@@ -50,3 +50,31 @@ def test_torchrun_world1_rccl_path_agrees_with_the_plain_run():
     assert a["n_gpus"] == b["n_gpus"] == 1 and b["config"]["rccl_nranks"] == 1 and a["config"]["rccl_nranks"] is None
     assert a["dtype"] == b["dtype"] and a["config"]["workload"] == b["config"]["workload"]
     assert abs(b["ms_per_step"] - a["ms_per_step"]) <= 0.10 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_driver_command_line_shape():
+    """The driver's own command: ONE JSON line whose headline, `roofline`, `cpu_baseline` and `setup` objects are self-consistent
+    (round 5: the step's build and the settle replays are setup, reported; the first K replays after the capture are timed beside
+    the headline; every MLP kernel carries its duration inside the step's kernel mix)."""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-pmc", "--cpu-seconds", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "rays/s" and d["higher_is_better"] is True
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None and "configs[2]" in d["config"]["workload"]
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert d["setup"]["build_calls_before_warmup"] == 4 and d["setup"]["settle_replays_before_warmup"] == 150
+    assert 0.9 * d["ms_per_step"] <= d["cold_start_ms_per_step"] <= 2.0 * d["ms_per_step"]
+    assert d["launches_per_step"] == 6
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and "mlp_bwd_dw_kernel" in roof["kernel"]
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 2e-3 and 0.15 <= roof["frac"] <= 0.45
+    assert roof["limited_by"] == "hbm" and 0.5 <= roof["hbm_view"]["frac"] <= 1.0 and "traffic" in roof
+    ks = d["roofline_kernels"]
+    assert len(ks) == 4 and all(k["in_step_launch_us"] > 0 and k["avg_launch_us"] > 0 for k in ks)
+    assert abs(sum(k["in_step_launch_us"] for k in ks) - d["mlp_kernels_us_per_step"]) <= 0.08 * d["mlp_kernels_us_per_step"]
+    assert abs(roof["avg_launch_us"] - max(k["in_step_launch_us"] for k in ks)) < 1e-6
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "rays/s" and cb["cores"] >= 1 and cb["value"] > 0 and "oracle" in cb["sample"]
