@@ -110,7 +110,7 @@ struct DwJobTable {
     const uint8_t* dys[kDwMaxJobs];    // dY slabs of the job's model
     int64_t ntiles[kDwMaxJobs];        // 32-point wave tiles of the job's model
     int njobs;
-    // bf16 (round 4): the sigma head's job has no workgroups of its own — its X is the final layer's X (h8: 16 slabs per tile that the
+    // (bf16: round 4; e4m3 and fp32: round 5)  The sigma head's job has no workgroups of its own — its X is the final layer's X (h8: 16 slabs per tile that the
     // launch used to read twice, 134 MB of its 2.87 GB) — so the FINAL layer's workgroups also form dW_sigma: fold_of[sigma job] = the
     // final job's index (its partial slabs hold the sigma partials in the tile column it does not use), -1 everywhere else.
     int fold_of[kDwMaxJobs];
