@@ -10,6 +10,8 @@ over xGMI on ROCm; "gloo" in the CPU tests).
   grad-ready hook of the fused backward, i.e. while the coarse model's backward is still running (autograd runs the
   fine model first); see `GradSync._on_grad_ready`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -56,6 +58,16 @@ def render_sharded(render_fn, rays, keys=("rgb_fine", "depth_fine", "opacity_fin
     return out
 
 
+_COALESCE = os.environ.get("NERFHIP_COALESCE_ALLREDUCE", "1") != "0"      # (A/B switch)
+
+
+class _Done:
+    """A finished piece of work (its collective was waited for as part of a group)."""
+
+    def wait(self):
+        return True
+
+
 class GradSync:
     """Average gradients across ranks (the reference's DDP, train.py:174-175): one all-reduce per model on the flat
     gradient buffer the dW-reduce kernel wrote (2.38 MB), else a flatten/all-reduce/unflatten of the parameter grads.
@@ -76,6 +88,7 @@ class GradSync:
                                     # must not contain the collective (two-graph mode)
         self._inflight = {}         # id(model) -> [(work, flat, needs_division)] issued from the hook since the last sync()
         self.started_early = 0      # statistics: all-reduces issued from the hook (tests assert on it)
+        self._coalesce = _COALESCE  # the per-model all-reduces of sync() as one grouped RCCL launch
         if overlap:
             self.attach()
 
@@ -148,7 +161,7 @@ class GradSync:
             return
         world = dist.get_world_size(self.group)
         op, div = self._avg_op()
-        works = []
+        works, direct = [], []
         for m in self.models:
             flat = getattr(m, "_flat_grad", None)
             early = self._inflight.pop(id(m), [])
@@ -168,10 +181,37 @@ class GradSync:
                                        "p.grad (autograd copied it while the collective was in flight); construct "
                                        "GradSync(overlap=False) for this training loop")
             if flat is not None and params and self._aliases(params, flat) and not early:
-                works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, None, div))
+                direct.append(flat)                                      # issued below, together
             elif params:
                 buf = torch.cat([p.grad.reshape(-1) for p in params])
                 works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf, params, div))
+        # The flat buffers that are reduced as they are (the two-graph step: nothing was started from the hooks): over RCCL as ONE
+        # grouped launch (ncclGroupStart / End around the per-model all-reduces: one kernel and one stream hand-over instead of one
+        # per model; same values — each buffer is still its own all-reduce), elsewhere (gloo: the CPU tests) one call each.
+        grouped = None
+        if len(direct) > 1 and self._coalesce and dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+            try:
+                with dist._coalescing_manager(group=self.group, async_ops=True) as grouped:
+                    for flat in direct:
+                        dist.all_reduce(flat, op=op, group=self.group)
+            except Exception as e:          # a stack without the grouped form: nothing was launched (the manager launches on exit);
+                import warnings             # every rank runs the same code on the same stack, so every rank lands here
+                warnings.warn("GradSync: grouped all-reduce unavailable (%r); one call per model from now on" % (e,))
+                self._coalesce = False
+                grouped = None
+                try:
+                    from torch.distributed import distributed_c10d as _c10d
+                    _c10d._world.pg_coalesce_state.pop(self.group or _c10d._get_default_group(), None)
+                except Exception:
+                    pass
+        if grouped is not None:
+            works.append((grouped, direct[0], None, False))
+            if div:
+                for flat in direct:
+                    works.append((_Done(), flat, None, True))
+        else:
+            for flat in direct:
+                works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, None, div))
         self._inflight.clear()
         for w, buf, params, need_div in works:
             w.wait()
