@@ -136,6 +136,22 @@ int main() {
         }
         CHECK(bwd_total_pieces(prec) == n && bwd_padded_pieces(prec) % kChunkPieces == 0, "bwd stream size");
     }
+    // ---- saved-tensor block addressing (round 5): piece p of wave tile t -> tile_block_off(t) + p * il KiB is a bijection onto the
+    // buffer for the plain (il = 1) and the interleaved (il = 8) layout, and il = 1 is the contiguous tile-major block ----
+    for (int il : {1, 8}) {
+        const int pieces = kActSlabs + kMaskPieces, tiles = 24, tile_bytes = pieces * kPieceBytes;
+        std::set<size_t> seen;
+        for (int t = 0; t < tiles; ++t)
+            for (int pc = 0; pc < pieces; ++pc) {
+                const size_t off = tile_block_off(t, tile_bytes, il) + (size_t)pc * il * kPieceBytes;
+                CHECK(off % kPieceBytes == 0 && off + kPieceBytes <= (size_t)tiles * tile_bytes, "il %d: tile %d piece %d out of the buffer", il, t, pc);
+                CHECK(seen.insert(off).second, "il %d: tile %d piece %d collides", il, t, pc);
+                if (il == 1) CHECK(off == (size_t)t * tile_bytes + (size_t)pc * kPieceBytes, "il 1 is tile-major (tile %d piece %d)", t, pc);
+                if (il == 8) CHECK(off / kPieceBytes % 8 == (size_t)(t % 8) && off / (8 * (size_t)tile_bytes) == (size_t)(t / 8), "il 8: octet / lane of tile %d piece %d", t, pc);
+            }
+        CHECK((int)seen.size() == tiles * pieces, "il %d covers the buffer", il);
+    }
+    CHECK(act_il(0) == 1 && act_il(1, true) == 1 && act_il(1) == NERFHIP_ACT_IL, "interleave applies to the bf16 slab blocks only");
     if (fails == 0) std::printf("layout ok\n");
     return fails ? 1 : 0;
 }
