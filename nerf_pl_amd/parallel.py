@@ -89,6 +89,7 @@ class GradSync:
         self._inflight = {}         # id(model) -> [(work, flat, needs_division)] issued from the hook since the last sync()
         self.started_early = 0      # statistics: all-reduces issued from the hook (tests assert on it)
         self._coalesce = _COALESCE  # the per-model all-reduces of sync() as one grouped RCCL launch
+        self._coalesce_backends = ("nccl",)     # (the gloo CPU test adds "gloo" to drive the same branch)
         if overlap:
             self.attach()
 
@@ -189,7 +190,8 @@ class GradSync:
         # grouped launch (ncclGroupStart / End around the per-model all-reduces: one kernel and one stream hand-over instead of one
         # per model; same values — each buffer is still its own all-reduce), elsewhere (gloo: the CPU tests) one call each.
         grouped = None
-        if len(direct) > 1 and self._coalesce and dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+        if (len(direct) > 1 and self._coalesce and dist.get_backend(self.group) in self._coalesce_backends
+                and hasattr(dist, "_coalescing_manager")):
             try:
                 with dist._coalescing_manager(group=self.group, async_ops=True) as grouped:
                     for flat in direct:

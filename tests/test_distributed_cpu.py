@@ -299,6 +299,53 @@ def _worker(rank, world, port, n_rays, q):
         except RuntimeError:
             pass
 
+        # --- round 5: the two-graph step's sync() issues the models' all-reduces as ONE grouped launch (RCCL: ncclGroupStart / End
+        # through torch's coalescing manager).  Same branch driven over gloo here: one manager entry for both buffers, the values
+        # of two separate calls; and when the grouped form raises, sync() falls back to one call per model for good.
+        def two_models():
+            ms_, flats_ = [], []
+            for k in range(2):
+                mm = _Tiny()
+                fl = base3 * (rank + 1) * (k + 1)
+                adopt(mm, fl)
+                mm._flat_grad = fl
+                ms_.append(mm)
+                flats_.append(fl)
+            return ms_, flats_
+        ms8, flats8 = two_models()
+        gs8 = parallel.GradSync(ms8)
+        gs8.hooks_enabled = False
+        gs8._coalesce_backends = ("nccl", "gloo")
+        entered = {"n": 0}
+        real_cm = dist._coalescing_manager
+
+        def counting_cm(*a, **kw):
+            entered["n"] += 1
+            return real_cm(*a, **kw)
+        dist._coalescing_manager = counting_cm
+        try:
+            gs8.sync()
+        finally:
+            dist._coalescing_manager = real_cm
+        ok_grouped = entered["n"] == 1 and gs8._coalesce and all(torch.allclose(f, base3 * want * (k + 1)) for k, f in enumerate(flats8))
+
+        def broken_cm(*a, **kw):
+            raise RuntimeError("no grouped collectives on this stack")
+        ms9, flats9 = two_models()
+        gs9 = parallel.GradSync(ms9)
+        gs9.hooks_enabled = False
+        gs9._coalesce_backends = ("nccl", "gloo")
+        dist._coalescing_manager = broken_cm
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gs9.sync()
+        finally:
+            dist._coalescing_manager = real_cm
+        ok_grouped = ok_grouped and not gs9._coalesce and all(torch.allclose(f, base3 * want * (k + 1)) for k, f in enumerate(flats9))
+        ok_overlap = ok_overlap and ok_grouped
+
         # --- the N>1 training step's host logic (system.GraphedTrainStep): eager warm-up steps, capture of
         # [forward+backward] and [optimizer] as two graphs with the collective issued eagerly in between, replays,
         # re-capture on a learning-rate change — with a recording stand-in for the hipGraph backend.
