@@ -1,0 +1,149 @@
+"""bench_inputs.py — constants and seeded synthetic inputs of bench.py (BASELINE.json: no dataset / checkpoint offline).
+
+Split out of bench.py in round 6 (no behaviour change): the algorithmic FLOP / byte constants of SURVEY §8(a)/(d), the hardware peaks
+of MI355X_MICROARCH.md, the seeded weights / rays / device-resident image stores, and `cpu_baseline()` — the ONLY function of the
+bench that touches the CPU checker under oracle/ (test infrastructure; the product never imports it).
+"""
+import os
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
+FLOP_PER_POINT_DX = 1115392        # backward chain: 557,696 MAC (no dX into the encodings)
+FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks of the forward / dX chain
+PEAK_TFLOPS_FP8 = 5000.0           # ... and of the MX-scaled fp8 MFMA the dW GEMM of bf16_f8 runs on
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+FLOP_PER_RAY_EVAL = 64 * 982528 + 192 * 1186816      # test_time render: sigma-only coarse pass + full fine pass (290.7 M)
+# `dtype` of the JSON line = the NARROWEST arithmetic inside the timed region
+DTYPE_LABEL = {"bf16_f8": "bf16+fp8(dW)", "bf16": "bf16", "fp32": "f32"}
+
+
+PARAM_SHAPES = [("xyz_encoding_%d.0" % (i + 1), 256, 63 if i == 0 else (319 if i == 4 else 256)) for i in range(8)] + \
+               [("xyz_encoding_final", 256, 256), ("dir_encoding.0", 128, 283), ("sigma", 1, 256), ("rgb.0", 3, 128)]
+
+
+def synth_params(seed, sigma_gain=1.0, sigma_bias=0.0):
+    """nn.Linear's default U(-1/sqrt(fan_in), 1/sqrt(fan_in)) from numpy PCG64 (identical on every rank and box);
+    the density head is rescaled so that opacity is non-trivial (a trained-like field)."""
+    import math
+
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, fo, fi in PARAM_SHAPES:
+        b = 1.0 / math.sqrt(fi)
+        p[name + ".weight"] = torch.from_numpy(rng.uniform(-b, b, size=(fo, fi)).astype(np.float32))
+        p[name + ".bias"] = torch.from_numpy(rng.uniform(-b, b, size=(fo,)).astype(np.float32))
+    p["sigma.weight"] = p["sigma.weight"] * sigma_gain
+    p["sigma.bias"] = p["sigma.bias"] * sigma_gain + sigma_bias
+    return p
+
+
+def synth_rays(seed, n):
+    """Blender-style rays (n,8): origins (0,0,4)+0.1N, unit directions aimed near the scene centre, near 2, far 6
+    (blender.py:34-35)."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(n, 3, generator=g)
+    d = 0.8 * torch.randn(n, 3, generator=g) - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return torch.cat([o, d, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0)], 1).float().contiguous()
+
+
+def cpu_baseline(B, S, N, seconds, train):
+    """The pinned CPU oracle (torch-CPU restatement of the reference's render_rays, kind='port') timed
+    on this node's host cores on the same workload shape; bounded to ~`seconds` of CPU work."""
+    from oracle import nerf_oracle as O
+    params = [O.make_params(0), O.make_params(1)]
+    rays = O.make_rays(0, B, "blender")
+    tgt = torch.rand(B, 3, generator=torch.Generator().manual_seed(0))
+    rng = O.draw_rng(0, B, S, N, 1.0)
+    if train:
+        for d in params:
+            for v in d.values():
+                v.requires_grad_(True)
+        opt = torch.optim.Adam([v for d in params for v in d.values()], lr=5e-4)
+
+    def one(rays_, tgt_, rng_):
+        if not train:
+            with torch.no_grad():
+                O.render_rays(params, rays_, S, False, 1.0, 0, N, True, False, rng=rng_)
+            return
+        res = O.render_rays(params, rays_, S, False, 1.0, 0, N, True, False, rng=rng_)
+        loss = O.mse_loss(res, tgt_)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))               # cores this process may run on (a container's cpuset)
+    except AttributeError:
+        usable = ncpu
+    # torch-CPU oversubscribes badly on many-core hosts: pick the fastest of a few thread counts on a
+    # 1/8-size probe, then time the full workload with it.
+    best, best_t = 1, float("inf")
+    Bp = max(32, B // 8)
+    sub = {k: v[:Bp] for k, v in rng.items()}
+    tried = sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)})
+    probe_ms = {}
+    for nt in tried:
+        torch.set_num_threads(nt)
+        one(rays[:Bp], tgt[:Bp], sub)
+        t0 = time.perf_counter()
+        one(rays[:Bp], tgt[:Bp], sub)
+        t = time.perf_counter() - t0
+        probe_ms[str(nt)] = round(t * 1e3, 1)
+        if t < best_t:
+            best, best_t = nt, t
+    torch.set_num_threads(best)
+    one(rays, tgt, rng)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one(rays, tgt, rng)
+        reps += 1
+        if time.perf_counter() - t0 > seconds or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    what = "training step (fwd+loss+bwd+Adam)" if train else "render_rays fwd"
+    # `cores` = the threads actually used (the contract's field); the node's own core count and what was tried ride beside it
+    return {"value": round(B * reps / dt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "node_cores": ncpu, "usable_cores": usable, "threads": torch.get_num_threads(), "threads_probe_ms": probe_ms,
+            "sample": "%d reps of the oracle's %s on %d rays x (%d+%d), torch-CPU fp32, %.1f s; %d threads = the fastest of %s on a 1/8-size "
+                      "probe, node has %d cores (%d usable)" % (reps, what, B, S, N, dt, torch.get_num_threads(), tried, ncpu, usable)}
+
+
+def synth_store(seed, dev, n_img=20, hw=200):
+    """Device-resident synthetic training set in the reference's Blender layout (blender.py:42-69): camera poses on a
+    radius-4 sphere looking at the origin + random pixel colours; batches are drawn and their rays generated on the GPU
+    (nerf_pl_amd.rays.RayStore), so a training batch never crosses PCIe."""
+    from nerf_pl_amd.rays import RayStore
+    g = torch.Generator().manual_seed(seed)
+    c = torch.nn.functional.normalize(torch.randn(n_img, 3, generator=g), dim=-1) * 4.0
+    fwd = torch.nn.functional.normalize(-c, dim=-1)                       # camera looks down its -z axis at the origin
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.nn.functional.normalize(torch.cross(fwd, up, dim=-1), dim=-1)
+    upv = torch.cross(right, fwd, dim=-1)
+    poses = torch.stack([right, upv, -fwd, c], -1).float().contiguous()   # (n_img, 3, 4) = [R | t]
+    rgbs = torch.rand(n_img * hw * hw, 3, generator=g)
+    return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.3, 2.0, 6.0)
+
+
+def synth_store_ndc(seed, dev, n_img=20, hw=200):
+    """The same in the reference's forward-facing LLFF layout (llff.py:236-253): cameras near the origin looking down -z with
+    small rotations, rays converted to NDC (near plane 1.0), bounds 0..1, non-unit directions."""
+    from nerf_pl_amd.rays import RayStore
+    g = torch.Generator().manual_seed(seed)
+    w = 0.1 * torch.randn(n_img, 3, generator=g)                          # small axis-angle rotations
+    K = torch.zeros(n_img, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    R = torch.matrix_exp(K)
+    t = 0.3 * torch.randn(n_img, 3, 1, generator=g)
+    poses = torch.cat([R, t], -1).float().contiguous()
+    rgbs = torch.rand(n_img * hw * hw, 3, generator=g)
+    return RayStore(poses.to(dev), rgbs.to(dev), hw, hw, 0.5 * hw / 0.35, 0.0, 1.0, use_ndc=True, ndc_near_plane=1.0)

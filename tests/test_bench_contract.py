@@ -57,9 +57,10 @@ def test_torchrun_world1_rccl_path_agrees_with_the_plain_run():
 
 @pytest.mark.gpu
 def test_driver_command_line_shape():
-    """The driver's own command: ONE JSON line whose headline, `roofline`, `cpu_baseline` and `setup` objects are self-consistent
-    (round 5: the step's build and the settle replays are setup, reported; the first K replays after the capture are timed beside
-    the headline; every MLP kernel carries its duration inside the step's kernel mix)."""
+    """The driver's own command: ONE JSON line whose headline, `literal_contract`, `protocol`, `roofline` and `cpu_baseline` objects are
+    self-consistent (round 6, protocol 3: build -> exactly W untimed + K timed steps = `literal_contract` -> settle replays -> W + K again
+    = `value`; every MLP kernel carries its duration inside the step's kernel mix; the CPU baseline states the node's core count AND
+    the threads it used)."""
     r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-pmc", "--cpu-seconds", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
@@ -68,8 +69,11 @@ def test_driver_command_line_shape():
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "rays/s" and d["higher_is_better"] is True
     assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None and "configs[2]" in d["config"]["workload"]
     assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
-    assert d["setup"]["build_calls_before_warmup"] == 4 and d["setup"]["settle_replays_before_warmup"] == 150
-    assert 0.8 * d["ms_per_step"] <= d["cold_start_ms_per_step"] <= 3.0 * d["ms_per_step"]
+    pr, lit = d["protocol"], d["literal_contract"]
+    assert pr["version"] == 3 and pr["build_calls_before_warmup"] == 4 and pr["settle_replays_since_build"] == 150 and "sustained" in pr["value_is"]
+    assert lit["warmup"] == 5 and lit["steps"] == 20 and abs(lit["value"] - 1024 / (lit["ms_per_step"] * 1e-3)) <= 1e-3 * lit["value"]
+    assert 0.8 * d["ms_per_step"] <= lit["ms_per_step"] <= 3.0 * d["ms_per_step"] and 0.05 <= lit["step_frac_mfma"] <= 0.6
+    assert "cold_start_ms_per_step" not in d and "setup" not in d
     assert d["launches_per_step"] == 6
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and "mlp_bwd_dw_kernel" in roof["kernel"]
@@ -81,3 +85,22 @@ def test_driver_command_line_shape():
     assert abs(roof["avg_launch_us"] - max(k["in_step_launch_us"] for k in ks)) < 1e-6
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "rays/s" and cb["cores"] >= 1 and cb["value"] > 0 and "oracle" in cb["sample"]
+    assert cb["node_cores"] == os.cpu_count() and cb["threads"] == cb["cores"] <= cb["node_cores"] and str(cb["threads"]) in cb["threads_probe_ms"]
+
+
+@pytest.mark.gpu
+def test_settle_0_reports_the_literal_contract_as_the_value():
+    r = _run(["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--settle", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["literal_contract"]["ms_per_step"] == d["ms_per_step"] and d["protocol"]["value_is"].startswith("literal_contract")
+
+
+@pytest.mark.gpu
+def test_workload_c3_is_a_main_step_of_its_own():
+    """configs[3] per GPU (NDC rays, noise_std 1, black background, 64 + 64) as the main step: what tools/ktrace_step.sh traces."""
+    r = _run(["--workload", "c3", "--steps", "10", "--warmup", "3", "--no-extras", "--no-pmc", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["N_importance"] == 64 and d["ms_per_step"] > 0
+    assert len(d["roofline_kernels"]) == 4

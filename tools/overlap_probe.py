@@ -15,6 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+import bench_extras  # noqa: E402
 
 
 def main():
@@ -78,7 +79,7 @@ def main():
 
     for name, fn in (("merged", merged), ("serial", serial), ("overlap_c", overlap("c", "f")), ("overlap_f", overlap("f", "c")),
                      ("merged", merged), ("overlap_c", overlap("c", "f"))):
-        avg, mn = bench.event_time(fn, 6, graph=True)
+        avg, mn = bench_extras.event_time(fn, 6, graph=True)
         print("%-10s %8.1f us avg  %8.1f us min" % (name, avg, mn), flush=True)
 
 
