@@ -73,8 +73,12 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="N=1: initialise the RCCL process group and route gradients through GradSync anyway (A/B of the N>1 step)")
     ap.add_argument("--sync-in-graph", type=int, default=None, choices=[0, 1],
-                    help="N>1 graphed step: 1 = ONE graph with the grad-ready-hook all-reduces inside (overlapped), 0 = two graphs "
-                         "with the collectives issued eagerly in between (default: GraphedTrainStep's)")
+                    help="N>1 graphed step: 1 = ONE graph with the hook-issued all-reduce(s) inside (the default since round 6; falls back to "
+                         "two graphs, agreed across the ranks, when a collective cannot be captured), 0 = two graphs with the collectives "
+                         "issued eagerly in between")
+    ap.add_argument("--grad-sync-form", default=None, choices=["merged", "per_model"],
+                    help="N>1: merged (default) = the one-rank launches + ONE all-reduce of the step's joint gradient buffer; per_model = "
+                         "the two models' backwards one after the other, the fine model's all-reduce under the coarse model's backward")
     return ap.parse_args()
 
 
@@ -226,7 +230,7 @@ def main():
 
     system, opt = build_system(a.dtype)
     models, emb = system.models, system.embeddings
-    grad_sync = GradSync(models, force=a.force_dist) if dist is not None else None
+    grad_sync = GradSync(models, force=a.force_dist, form=a.grad_sync_form) if dist is not None else None
     rays = synth_rays(1234 + rank, B).to(dev)                 # fixed batch: render mode, per-kernel timings
     # each rank owns its own images and draws its own batches
     store = synth_store_ndc(777 + rank, dev) if c3 else synth_store(4321 + rank, dev)
@@ -397,7 +401,7 @@ def main():
                                       "source": "profiles/archive/r02_probe_mfma_rate.txt"}
         if a.mode == "train":
             # ---- the kernels the TIMED step runs, one entry each; `roofline` = the one that takes the most time ----
-            table, mix_us = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db, merged=(system.fused_train_step and grad_sync is None))
+            table, mix_us = kernel_table(models, rays, S, N, a.dtype, dev, traffic_db, merged=(system.fused_train_step and (grad_sync is None or grad_sync.form == "merged")))
             dom = max(table, key=lambda r: r["in_step_launch_us"])
             # The headline figure follows SURVEY 8(d): an MLP kernel is priced against the dense MFMA peak of its arithmetic with the
             # ALGORITHMIC FLOPs of the GEMMs it performs.  The HBM view of the same launch (this design materialises activations
@@ -478,10 +482,13 @@ def main():
                        "rccl_nranks": rccl_nranks,
                        "capture_fallback": (getattr(state["graphed"], "capture_fallback", None) if a.mode == "train" else None),
                        "grad_sync": (None if (grad_sync is None or a.mode != "train") else
-                                     ("one hipGraph, all-reduces issued from the grad-ready hooks inside it"
-                                      if (state["graphed"] is not None and not state["graphed"]._two_graphs()) else
-                                      "two hipGraphs (fwd+bwd | Adam), flat-buffer all-reduces issued eagerly in between"
-                                      if state["graphed"] is not None else "eager, hook-overlapped all-reduces"))},
+                                     (("one hipGraph, all-reduce(s) issued from the backward's hook inside it"
+                                       if (state["graphed"] is not None and not state["graphed"]._two_graphs()) else
+                                       "two hipGraphs (fwd+bwd | Adam), flat-buffer all-reduce(s) issued eagerly in between"
+                                       if state["graphed"] is not None else "eager, hook-issued all-reduce(s)")
+                                      + ("; form=merged: the one-rank launches + ONE all-reduce over the step's joint gradient buffer (4.77 MB)"
+                                         if grad_sync.form == "merged" else
+                                         "; form=per_model: per model chain -> dW -> reduce -> all-reduce (2.38 MB each)")))},
         }
         per_step_rays = a.image_rays if a.mode == "eval" else world * B
         lit = {"ms_per_step": round(dt_literal / a.steps * 1e3, 4), "value": round(per_step_rays * a.steps / dt_literal, 1), "unit": "rays/s",

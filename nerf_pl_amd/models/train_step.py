@@ -121,9 +121,19 @@ class _TrainRender(torch.autograd.Function):
         for m, serial in zip(models, ctx.serials):
             m.check_pack_serial(serial)
         hooked = any(getattr(m, "_grad_ready_hook", None) is not None for m in models)
-        if hooked:
-            # N > 1 ranks: per model chain -> dW -> reduce -> grad-ready hook, so that the fine model's all-reduce travels
-            # while the coarse model's backward still runs (parallel.GradSync)
+        joint_hook = getattr(models[0], "_grads_ready_hook", None) if hooked else None
+        if hooked and joint_hook is not None and all(getattr(m, "_grads_ready_hook", None) == joint_hook for m in models):
+            # N > 1 ranks, the default form (parallel.GradSync(form="merged")): the SAME launches as the one-rank step — one chain,
+            # one dW, one reduce launch for both models — and then ONE all-reduce over the step's gradients, which the launch wrote as
+            # consecutive slices of one buffer.  (Measured at world 1: the per-model form below costs 7.6 % of the step before any
+            # wire time — two dW launches fill the chip worse than one; a single 4.77 MB all-reduce exposes less than that.)
+            grads = ops.mlp_bwd_multi(entries, dtype, g_scale=g_scale)
+            for m, g in zip(models, grads):
+                m._flat_grad = g[2]
+            joint_hook(models, [g[2] for g in grads])
+        elif hooked:
+            # N > 1 ranks, form="per_model": per model chain -> dW -> reduce -> grad-ready hook, so that the fine model's all-reduce
+            # travels while the coarse model's backward still runs (parallel.GradSync)
             grads = []
             for m, (g_out, out, packed_bwd, acts) in zip(models, entries):
                 ((gw, gb, flat),) = ops.mlp_bwd_multi([(g_out, out, packed_bwd, acts)], dtype, g_scale=g_scale)

@@ -744,10 +744,20 @@ def pack_models_train(models, dtype):
     return bufs
 
 
-def flat_grad_views(n_points, device, shapes=PARAM_SHAPES):
-    """One flat fp32 buffer for a model's 24 gradients + the 12 weight and 12 bias views of it (the layout FlatAdam mirrors)."""
+FLAT_GRAD_FLOATS = sum(s[0] * s[1] + s[0] for s in PARAM_SHAPES)      # 595,844: a model's 24 gradients (16-byte multiple)
+
+
+def flat_grad_views(n_points, device, shapes=PARAM_SHAPES, out=None):
+    """One flat fp32 buffer for a model's 24 gradients + the 12 weight and 12 bias views of it (the layout FlatAdam mirrors).
+    out: the slice of a larger buffer to use as that flat buffer (mlp_bwd_multi: the models' buffers are consecutive slices of ONE
+    allocation, so that the gradients of a whole step are one contiguous message for the all-reduce)."""
     sizes = [s[0] * s[1] for s in shapes] + [s[0] for s in shapes]
-    flat = (torch.zeros if n_points == 0 else torch.empty)(sum(sizes), device=device, dtype=torch.float32)
+    if out is not None:
+        flat = out
+        if n_points == 0:
+            flat.zero_()
+    else:
+        flat = (torch.zeros if n_points == 0 else torch.empty)(sum(sizes), device=device, dtype=torch.float32)
     views, off = [], 0
     for sz in sizes:
         views.append(flat[off:off + sz])
@@ -782,8 +792,11 @@ def mlp_bwd_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=N
             ws = torch.empty(int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, M, code)), device=dev, dtype=torch.uint8)
             if workspace is not None:
                 workspace[key] = (dys, ws)
-        for n in ns:
-            grads.append(flat_grad_views(n, dev))
+        # the M flat gradient buffers are consecutive slices of ONE allocation (`flat._base`): parallel.GradSync all-reduces a step's
+        # gradients as one message
+        joint = torch.empty(M * FLAT_GRAD_FLOATS, device=dev, dtype=torch.float32)
+        for m, n in enumerate(ns):
+            grads.append(flat_grad_views(n, dev, out=joint[m * FLAT_GRAD_FLOATS:(m + 1) * FLAT_GRAD_FLOATS]))
         vp = ctypes.c_void_p
         G = (vp * M)(*[t.data_ptr() for t in gs])
         O = (vp * M)(*[t.data_ptr() for t in outs])

@@ -5,10 +5,13 @@ over xGMI on ROCm; "gloo" in the CPU tests).
   collective on the data path and one gather of the finished pixels (eval.py:58-86 sharded).
 * Training is the reference's DDP (train.py:174-175): replicated models, each rank draws its own
   batch, gradients are averaged.  Each model's 24 gradients live in ONE flat fp32 buffer written by
-  the dW-reduce kernel (2.38 MB), so a step needs exactly one all-reduce per model — a message that on
-  the 8-GPU xGMI mesh is latency-bound (~10 us of wire time).  `GradSync` issues the fine model's all-reduce from a
-  grad-ready hook of the fused backward, i.e. while the coarse model's backward is still running (autograd runs the
-  fine model first); see `GradSync._on_grad_ready`.
+  the dW-reduce kernel (2.38 MB), and the fused step's backward writes both models' buffers as consecutive
+  slices of one allocation: a step needs exactly ONE all-reduce (4.77 MB) — a message that on the 8-GPU xGMI
+  mesh is latency-bound.  `GradSync(form="merged")` (the default) keeps the one-rank step's launches (one chain, one dW,
+  one reduce launch for both models) and issues that all-reduce from the backward's grads-ready hook;
+  `form="per_model"` runs the two models' backwards one after the other and issues the fine model's all-reduce while the
+  coarse model's backward is still running (autograd runs the fine model first; `GradSync._on_grad_ready`) — what DDP's
+  bucket hooks give the reference, at the price of un-merging the launches (7.6 % of the step at world 1).
 """
 import os
 
@@ -79,11 +82,18 @@ class GradSync:
     compositing / importance sampling / the coarse model's backward still execute; `sync()` then waits for whatever
     was started, launches whatever was not, and divides by the world size."""
 
-    def __init__(self, models, group=None, force=False, overlap=True):
+    def __init__(self, models, group=None, force=False, overlap=True, form=None):
         self.models = list(models)
         self.group = group
         self.force = force          # run the collectives even at world size 1 (tests the RCCL path on one GPU)
         self.overlap = overlap
+        # form of the fused step's backward under this sync: "merged" = the one-rank launches + ONE all-reduce of the step's joint
+        # gradient buffer; "per_model" = per model chain -> dW -> reduce -> all-reduce (the fine model's travels under the coarse
+        # model's backward).  NERFHIP_GRAD_SYNC_FORM overrides the default for A/B runs (tools/launch_scale.sh measures both).
+        self.form = form if form is not None else os.environ.get("NERFHIP_GRAD_SYNC_FORM", "merged")
+        if self.form not in ("merged", "per_model"):
+            raise ValueError("GradSync form must be 'merged' or 'per_model', got %r" % (self.form,))
+        self.issue_log = []         # ("model", id(model)) / ("joint", n_models) per hook-issued collective since the last sync() (tests)
         self.hooks_enabled = True   # GraphedTrainStep switches the hooks off while it captures/replays a graph that
                                     # must not contain the collective (two-graph mode)
         self._inflight = {}         # id(model) -> [(work, flat, needs_division)] issued from the hook since the last sync()
@@ -100,11 +110,14 @@ class GradSync:
     def attach(self):
         for m in self.models:
             m._grad_ready_hook = self._on_grad_ready
+            m._grads_ready_hook = self._on_grads_ready if self.form == "merged" else None
 
     def detach(self):
         for m in self.models:
             if getattr(m, "_grad_ready_hook", None) == self._on_grad_ready:
                 m._grad_ready_hook = None
+            if getattr(m, "_grads_ready_hook", None) == self._on_grads_ready:
+                m._grads_ready_hook = None
 
     def agree_any(self, flag):
         """True on every rank if `flag` is true on any (one small eager MAX all-reduce): ranks that must take the same branch —
@@ -139,6 +152,44 @@ class GradSync:
         work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self._inflight.setdefault(id(model), []).append([work, flat, div, False])
         self.started_early += 1
+        self.issue_log.append(("model", id(model)))
+
+    @staticmethod
+    def joint_of(flats):
+        """The ONE tensor whose consecutive slices `flats` are (ops.mlp_bwd_multi allocates a step's flat gradient buffers that
+        way), or None."""
+        base = getattr(flats[0], "_base", None)
+        if base is None or any(getattr(f, "_base", None) is not base for f in flats) or not base.is_contiguous():
+            return None
+        off = flats[0].storage_offset()
+        for f in flats:
+            if f.storage_offset() != off or not f.is_contiguous():
+                return None
+            off += f.numel()
+        lo = flats[0].storage_offset() - base.storage_offset()
+        return base.reshape(-1)[lo:lo + sum(f.numel() for f in flats)]
+
+    def _on_grads_ready(self, models, flats):
+        """form="merged": called ONCE by the fused backward when the flat gradient buffers of ALL its models are complete (one
+        reduce launch wrote them), BEFORE autograd hands the views to the parameters.  Issues ONE all-reduce over the joint buffer,
+        asynchronously on the communicator's stream; the same adoption rule as `_on_grad_ready`."""
+        if not (self.hooks_enabled and self.overlap and self.active()):
+            return
+        for m in models:
+            self._finish(self._inflight.get(id(m), ()))
+        self._finish(self._inflight.get("joint", ()))
+        if any(p.grad is not None for m in models for p in m.parameters()):
+            return                                     # gradient accumulation: sync() reduces the accumulated p.grad
+        joint = self.joint_of(flats)
+        if joint is None:                              # not one allocation (an older caller): one collective per model
+            for m, f in zip(models, flats):
+                self._on_grad_ready(m, f)
+            return
+        op, div = self._avg_op()
+        work = dist.all_reduce(joint, op=op, group=self.group, async_op=True)
+        self._inflight.setdefault("joint", []).append([work, joint, div, False, [id(m) for m in models], list(flats)])
+        self.started_early += 1
+        self.issue_log.append(("joint", len(models)))
 
     def _finish(self, entries):
         """wait for hook-issued collectives and apply their division: afterwards each buffer holds the rank average"""
@@ -163,7 +214,33 @@ class GradSync:
         world = dist.get_world_size(self.group)
         op, div = self._avg_op()
         works, direct = [], []
+        del self.issue_log[:-64]                        # (a diagnostic: keep the tail)
+        covered = set()
+        early_joint = self._inflight.pop("joint", [])
+        if len(early_joint) == 1 and not early_joint[0][3]:
+            work, joint, jdiv, _, mids, flats = early_joint[0]
+            by_id = {id(m): m for m in self.models}
+            ok = all(i in by_id for i in mids)
+            for i, f in zip(mids, flats):
+                ps = [p for p in by_id[i].parameters() if p.grad is not None] if ok else []
+                ok = ok and bool(ps) and getattr(by_id[i], "_flat_grad", None) is f and self._aliases(ps, f) and not self._inflight.get(i)
+            if ok:
+                works.append((work, joint, None, jdiv))                     # the hook-issued collective IS the step's gradient
+                covered.update(mids)
+        if not covered:
+            # a joint collective whose buffers are not simply p.grad any more (a later backward accumulated on top): finish it,
+            # then reduce p.grad below — exact, as for the per-model case
+            self._finish(early_joint)
+            for e in early_joint:
+                for i, f in zip(e[4], e[5]):
+                    ps = [p for m in self.models if id(m) == i for p in m.parameters() if p.grad is not None]
+                    if ps and not self._aliases(ps, f):
+                        raise RuntimeError("GradSync: the gradient buffer all-reduced from the grads-ready hook was not adopted as "
+                                           "p.grad (autograd copied it while the collective was in flight); construct "
+                                           "GradSync(overlap=False) for this training loop")
         for m in self.models:
+            if id(m) in covered:
+                continue
             flat = getattr(m, "_flat_grad", None)
             early = self._inflight.pop(id(m), [])
             params = [p for p in m.parameters() if p.grad is not None]
@@ -186,26 +263,36 @@ class GradSync:
             elif params:
                 buf = torch.cat([p.grad.reshape(-1) for p in params])
                 works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf, params, div))
-        # The flat buffers that are reduced as they are (the two-graph step: nothing was started from the hooks): over RCCL as ONE
-        # grouped launch (ncclGroupStart / End around the per-model all-reduces: one kernel and one stream hand-over instead of one
-        # per model; same values — each buffer is still its own all-reduce), elsewhere (gloo: the CPU tests) one call each.
+        # The flat buffers that are reduced as they are (the two-graph step: nothing was started from the hooks).  The fused step's
+        # backward wrote them as consecutive slices of one allocation: ONE all-reduce over that range.  Buffers that are not adjacent
+        # (a modular-graph step) go over RCCL as ONE grouped launch (ncclGroupStart / End around the per-model all-reduces: same
+        # values — each buffer is still its own all-reduce), elsewhere (gloo: the CPU tests) one call each.
         grouped = None
+        joint = self.joint_of(direct) if len(direct) > 1 else None
+        if joint is not None:
+            works.append((dist.all_reduce(joint, op=op, group=self.group, async_op=True), joint, None, div))
+            direct = []
         if (len(direct) > 1 and self._coalesce and dist.get_backend(self.group) in self._coalesce_backends
                 and hasattr(dist, "_coalescing_manager")):
+            # Only a stack WITHOUT the grouped form is a reason to fall back, and only before anything can have launched: the manager
+            # launches on __exit__, so an error from inside the block or from the exit (a communicator error, a partial enqueue) is
+            # re-raised — re-issuing after it would double or mismatch collectives across the ranks.
             try:
-                with dist._coalescing_manager(group=self.group, async_ops=True) as grouped:
+                cm = dist._coalescing_manager(group=self.group, async_ops=True)
+                grouped = cm.__enter__()
+            except (AttributeError, TypeError, NotImplementedError) as e:
+                import warnings
+                warnings.warn("GradSync: grouped all-reduce unavailable on this stack (%r); one call per model from now on" % (e,))
+                self._coalesce = False
+                cm = grouped = None
+            if cm is not None:
+                try:
                     for flat in direct:
                         dist.all_reduce(flat, op=op, group=self.group)
-            except Exception as e:          # a stack without the grouped form: nothing was launched (the manager launches on exit);
-                import warnings             # every rank runs the same code on the same stack, so every rank lands here
-                warnings.warn("GradSync: grouped all-reduce unavailable (%r); one call per model from now on" % (e,))
-                self._coalesce = False
-                grouped = None
-                try:
-                    from torch.distributed import distributed_c10d as _c10d
-                    _c10d._world.pg_coalesce_state.pop(self.group or _c10d._get_default_group(), None)
-                except Exception:
-                    pass
+                except BaseException as e:
+                    cm.__exit__(type(e), e, e.__traceback__)
+                    raise
+                cm.__exit__(None, None, None)
         if grouped is not None:
             works.append((grouped, direct[0], None, False))
             if div:

@@ -204,12 +204,13 @@ class GraphedTrainStep:
     time.  The first `warmup` calls run eagerly on the real batches (they are ordinary training steps), the next call
     captures and then replays.  A learning-rate change (scheduler) triggers a re-capture.
 
-    With a `grad_sync` (N > 1 ranks) the step is by default TWO graphs — [forward + backward] and [optimizer] — with the
-    all-reduce of the two flat gradient buffers issued eagerly in between.  `sync_in_graph=True` (or NERFHIP_SYNC_IN_GRAPH=1)
-    makes it ONE graph: the all-reduces the grad-ready hooks issue are captured inside it (RCCL supports capture) and overlap
-    the rest of the backward on replay; opt-in until a real N > 1 run has validated it (it falls back to two graphs, agreed
-    across the ranks, when the capture fails).  World-1 A/B on one MI355X (RCCL communicator of one rank, profiles/README.md round 3): one graph
-    0.957 ms, two graphs 0.982 ms, no communicator 0.908 ms per step.
+    With a `grad_sync` (N > 1 ranks) the step is by default ONE graph (round 6): the all-reduce the backward's grads-ready hook
+    issues (parallel.GradSync: one 4.77 MB message over the step's joint gradient buffer; per model under form="per_model") is
+    captured inside it (RCCL supports capture) between the reduce launch and Adam, and the host touches the step once.  When the
+    capture of a collective fails on ANY rank the ranks agree (GradSync.agree_any, an eager collective outside every capture) to
+    fall back to TWO graphs — [forward + backward] and [optimizer] — with the all-reduce issued eagerly in between: the form
+    `sync_in_graph=False` / NERFHIP_SYNC_IN_GRAPH=0 selects outright.  World-1 A/B on one MI355X (RCCL communicator of one rank):
+    profiles/README.md round 6.
     Outputs are static tensors overwritten by every replay (clone what you keep)."""
 
     def __init__(self, system, optimizer, grad_sync=None, warmup=3, sync_in_graph=None, backend=None, batch_source=None):
@@ -220,12 +221,12 @@ class GraphedTrainStep:
         self.batch_source = batch_source
         self._seed = None
         self.warmup = warmup
-        # N > 1 ranks: TWO graphs with the all-reduces issued eagerly in between is the default — the form whose every piece has
-        # run on hardware (hipGraph replay at world 1, eager RCCL all-reduce).  ONE graph with the collectives captured inside
-        # (sync_in_graph=True, NERFHIP_SYNC_IN_GRAPH=1; 25 us faster at world 1) has never met a real N > 1 communicator — no
-        # multi-GPU node was available to any round — so it is opt-in until a hardware run has validated it.
+        # N > 1 ranks: ONE graph with the collective captured inside is the default (round 6); every rank that cannot capture it
+        # makes all ranks fall back to two graphs with the all-reduce issued eagerly in between (_capture below), so the first
+        # hardware run at N > 1 meets the fast form and still completes on a stack that refuses it.  NERFHIP_SYNC_IN_GRAPH=0 /
+        # sync_in_graph=False selects the two-graph form outright.
         if sync_in_graph is None:
-            sync_in_graph = os.environ.get("NERFHIP_SYNC_IN_GRAPH", "0") == "1"
+            sync_in_graph = os.environ.get("NERFHIP_SYNC_IN_GRAPH", "1") != "0"
         self.sync_in_graph = bool(sync_in_graph)
         self.calls = 0
         self.graph = None

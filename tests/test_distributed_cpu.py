@@ -115,13 +115,13 @@ def _graphed_step_host_logic(rank, world):
         ropt.step()
     rflat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
     ok = bool(ok and torch.allclose(flat, rflat, rtol=1e-5, atol=1e-6))
-    # the default IS the two-graph form (one graph is opt-in until a real N > 1 run has validated it)
-    ok = ok and GraphedTrainStep(sysm, opt, grad_sync=sync, backend=_RecordingBackend())._two_graphs()
-    # the opt-in N > 1 form: ONE graph with the collectives inside (issued by sync() during the captured step) — same replicas
+    # the default IS the one-graph form (round 6; the two-graph form is the agreed fallback and an explicit choice)
+    ok = ok and not GraphedTrainStep(sysm, opt, grad_sync=sync, backend=_RecordingBackend())._two_graphs()
+    # the default N > 1 form: ONE graph with the collectives inside (issued by sync() during the captured step) — same replicas
     sys1 = _TinySystem()
     opt1 = torch.optim.SGD(sys1.parameters(), lr=0.1)
     be1 = _RecordingBackend()
-    step1 = GraphedTrainStep(sys1, opt1, grad_sync=parallel.GradSync(sys1.models), warmup=2, backend=be1, sync_in_graph=True)
+    step1 = GraphedTrainStep(sys1, opt1, grad_sync=parallel.GradSync(sys1.models), warmup=2, backend=be1)
     for i, b in enumerate(batches):
         if i == 5:
             for grp in opt1.param_groups:
@@ -178,6 +178,63 @@ def _graphed_step_host_logic(rank, world):
     ok = ok and step3.capture_fallback is not None and step3._two_graphs() and step3.graph_opt is not None
     ok = ok and (("another rank" in step3.capture_fallback) == (rank != 1))
     return bool(ok and torch.allclose(flat3, rflat, rtol=1e-5, atol=1e-6))
+
+
+def _fused_backward_issue_order(rank, world):
+    """The fused training node's backward (models/train_step._TrainRender.backward) under the two GradSync forms, with the HIP
+    launch (ops.mlp_bwd_multi) replaced by a recorder: WHAT is launched and WHEN the collectives are issued relative to it.
+      form="per_model": fine chain/dW/reduce -> the fine model's all-reduce is ISSUED -> only then the coarse model's launches;
+      form="merged" (default): ONE launch for both models -> ONE all-reduce over the joint buffer."""
+    from types import SimpleNamespace
+
+    from nerf_pl_amd import ops
+    from nerf_pl_amd.models import NeRF
+    from nerf_pl_amd.models import train_step as TS
+    ok = True
+    real_multi, real_ar = ops.mlp_bwd_multi, dist.all_reduce
+    for form in ("per_model", "merged"):
+        torch.manual_seed(3)
+        coarse, fine = NeRF(), NeRF()
+        gs = parallel.GradSync([coarse, fine], form=form)
+        log = []
+
+        def fake_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=None):
+            log.append(("launch", tuple(e[0] for e in entries)))
+            joint = torch.empty(len(entries) * ops.FLAT_GRAD_FLOATS)
+            out = []
+            for k, e in enumerate(entries):
+                fl = joint[k * ops.FLAT_GRAD_FLOATS:(k + 1) * ops.FLAT_GRAD_FLOATS]
+                fl.fill_(float(rank + 1) * (1.0 if e[0] == "fine" else 3.0))
+                out.append(ops.flat_grad_views(1, "cpu", out=fl))
+            return out
+
+        def logging_ar(t, *a_, **kw_):
+            log.append(("all_reduce", t.numel()))
+            return real_ar(t, *a_, **kw_)
+        ops.mlp_bwd_multi, dist.all_reduce = fake_multi, logging_ar
+        try:
+            ctx = SimpleNamespace(n_params=[24, 24], entries=[("fine", None, None, None), ("coarse", None, None, None)], dtype="bf16",
+                                  adam=None, models=[fine, coarse], serials=[0, 0])
+            grads = TS._TrainRender.backward(ctx, torch.ones(()))
+            # autograd adopts the returned views as p.grad (parameter order of forward(): coarse, then fine)
+            for p_, g_ in zip(coarse.flat_params() + fine.flat_params(), grads[3:]):
+                p_.grad = g_
+            issued = list(log)
+            gs.sync()
+        finally:
+            ops.mlp_bwd_multi, dist.all_reduce = real_multi, real_ar
+        n = ops.FLAT_GRAD_FLOATS
+        if form == "per_model":
+            ok = ok and issued == [("launch", ("fine",)), ("all_reduce", n), ("launch", ("coarse",)), ("all_reduce", n)]
+            ok = ok and gs.issue_log[:2] == [("model", id(fine)), ("model", id(coarse))]
+        else:
+            ok = ok and issued == [("launch", ("fine", "coarse")), ("all_reduce", 2 * n)] and gs.issue_log[:1] == [("joint", 2)]
+        ok = ok and len(log) == len(issued)                                   # sync() only waited: no further collective
+        want = (world + 1) / 2.0
+        ok = ok and all(torch.allclose(p_.grad, torch.full_like(p_, want)) for p_ in fine.parameters())
+        ok = ok and all(torch.allclose(p_.grad, torch.full_like(p_, 3.0 * want)) for p_ in coarse.parameters())
+        gs.detach()
+    return bool(ok)
 
 
 def _worker(rank, world, port, n_rays, q):
@@ -329,8 +386,8 @@ def _worker(rank, world, port, n_rays, q):
             dist._coalescing_manager = real_cm
         ok_grouped = entered["n"] == 1 and gs8._coalesce and all(torch.allclose(f, base3 * want * (k + 1)) for k, f in enumerate(flats8))
 
-        def broken_cm(*a, **kw):
-            raise RuntimeError("no grouped collectives on this stack")
+        def broken_cm(*a, **kw):                                # a stack WITHOUT the grouped form: the only reason to fall back
+            raise NotImplementedError("no grouped collectives on this stack")
         ms9, flats9 = two_models()
         gs9 = parallel.GradSync(ms9)
         gs9.hooks_enabled = False
@@ -344,7 +401,92 @@ def _worker(rank, world, port, n_rays, q):
         finally:
             dist._coalescing_manager = real_cm
         ok_grouped = ok_grouped and not gs9._coalesce and all(torch.allclose(f, base3 * want * (k + 1)) for k, f in enumerate(flats9))
+        #  any OTHER error — a communicator error, a failure after a partial enqueue — is re-raised, never papered over by
+        # re-issuing the collectives one by one (they could run twice, or mismatch across the ranks): every rank raises alike here
+        def failing_cm(*a, **kw):
+            raise RuntimeError("communicator error")
+        ms10, flats10 = two_models()
+        gs10 = parallel.GradSync(ms10)
+        gs10.hooks_enabled = False
+        gs10._coalesce_backends = ("nccl", "gloo")
+        dist._coalescing_manager = failing_cm
+        try:
+            gs10.sync()
+            ok_grouped = False
+        except RuntimeError:
+            ok_grouped = ok_grouped and gs10._coalesce and all(torch.allclose(f, base3 * (rank + 1) * (k + 1)) for k, f in enumerate(flats10))
+        finally:
+            dist._coalescing_manager = real_cm
         ok_overlap = ok_overlap and ok_grouped
+
+        # --- round 6: the fused step's backward writes both models' flat buffers as consecutive slices of ONE allocation
+        # (ops.mlp_bwd_multi) and announces them together; GradSync(form="merged") — the default — issues ONE all-reduce over the
+        # joint buffer from that hook, and sync() only waits.  With the hooks off (the two-graph fallback) sync() itself sends the
+        # joint range as one message: no coalescing manager involved.
+        def joint_models(scale):
+            ms_ = [_Tiny(), _Tiny()]
+            n_ = sum(sizes)
+            joint_ = torch.empty(2 * n_)
+            flats_ = [joint_[k * n_:(k + 1) * n_] for k in range(2)]
+            for k, fl in enumerate(flats_):
+                fl.copy_(base3 * (rank + 1) * (k + 1) * scale)
+                ms_[k]._flat_grad = fl
+            return ms_, flats_, joint_
+        ms11, flats11, joint11 = joint_models(1.0)
+        gs11 = parallel.GradSync(ms11)
+        calls11 = {"n": 0, "numel": []}
+        real_ar = dist.all_reduce
+
+        def counting_ar(t, *a_, **kw_):
+            calls11["n"] += 1
+            calls11["numel"].append(t.numel())
+            return real_ar(t, *a_, **kw_)
+        dist.all_reduce = counting_ar
+        try:
+            ok_joint = gs11.form == "merged" and ms11[0]._grads_ready_hook is not None and ms11[0]._grads_ready_hook == ms11[1]._grads_ready_hook
+            ms11[0]._grads_ready_hook(ms11, flats11)             # what models/train_step._TrainRender.backward does (p.grad still None)
+            ok_joint = ok_joint and calls11["n"] == 1 and calls11["numel"] == [2 * sum(sizes)] and gs11.issue_log == [("joint", 2)]
+            for mm, fl in zip(ms11, flats11):
+                adopt(mm, fl)
+            gs11.sync()
+            ok_joint = ok_joint and calls11["n"] == 1 and not gs11._inflight       # sync() only waited
+            ok_joint = ok_joint and all(torch.allclose(f, base3 * want * (k + 1)) for k, f in enumerate(flats11))
+            # hooks off: sync() sends the joint range itself, as ONE message
+            ms12, flats12, _ = joint_models(2.0)
+            gs12 = parallel.GradSync(ms12)
+            gs12.hooks_enabled = False
+            gs12._coalesce_backends = ("nccl", "gloo")
+            entered["n"] = 0
+            dist._coalescing_manager = counting_cm
+            calls11["n"], calls11["numel"] = 0, []
+            ms12[0]._grads_ready_hook(ms12, flats12)
+            for mm, fl in zip(ms12, flats12):
+                adopt(mm, fl)
+            gs12.sync()
+            ok_joint = ok_joint and calls11["n"] == 1 and calls11["numel"] == [2 * sum(sizes)] and entered["n"] == 0
+            ok_joint = ok_joint and all(torch.allclose(f, base3 * want * (k + 1) * 2.0) for k, f in enumerate(flats12))
+            # gradient accumulation under the joint hook: nothing is issued early, sync() averages the accumulated p.grad
+            ms13, flats13, _ = joint_models(1.0)
+            gs13 = parallel.GradSync(ms13)
+            for mm in ms13:
+                for p_ in mm.parameters():
+                    p_.grad = torch.full_like(p_, 10.0 * (rank + 1))
+            calls11["n"] = 0
+            ms13[0]._grads_ready_hook(ms13, flats13)
+            ok_joint = ok_joint and calls11["n"] == 0
+            for mm, fl in zip(ms13, flats13):
+                off = 0
+                for p_, sz in zip(mm.parameters(), sizes):
+                    p_.grad += fl[off:off + sz].view_as(p_)
+                    off += sz
+            gs13.sync()
+            got13 = [torch.cat([p_.grad.reshape(-1) for p_ in mm.parameters()]) for mm in ms13]
+            ok_joint = ok_joint and all(torch.allclose(g_, base3 * want * (k + 1) + 10.0 * want) for k, g_ in enumerate(got13))
+        finally:
+            dist.all_reduce = real_ar
+            dist._coalescing_manager = real_cm
+        ok_overlap = ok_overlap and ok_joint
+        ok_overlap = ok_overlap and _fused_backward_issue_order(rank, world)
 
         # --- the N>1 training step's host logic (system.GraphedTrainStep): eager warm-up steps, capture of
         # [forward+backward] and [optimizer] as two graphs with the collective issued eagerly in between, replays,
