@@ -423,6 +423,11 @@ typedef struct nerfhip_render_args {
 int nerfhip_render_supported(int64_t B, int S_c, int N_i, int dtype);
 /* inference: rgb / depth / opacity of both passes (the training-only fields are ignored) */
 int nerfhip_render_fwd(const nerfhip_render_args* args_host, int dtype, nerfhip_stream_t stream);
+/* inference under test_time (rendering.py:209-213; what eval.py:69-79 asks for): the coarse network stops at its density head
+ * (nerf.py:112-114 sigma_only), so raw_coarse is (B,S_c) — sigma alone — and the coarse pass leaves opacity_coarse only
+ * (rgb_coarse / depth_coarse are ignored); N_i > 0.  Bit-identical to nerfhip_mlp_fwd_rays_coarse(sigma_only) ->
+ * nerfhip_composite_fwd -> nerfhip_fine_z -> nerfhip_mlp_fwd_rays -> nerfhip_composite_fwd.                                    */
+int nerfhip_render_test_fwd(const nerfhip_render_args* args_host, int dtype, nerfhip_stream_t stream);
 /* The forward of a training step (train.py:103-117 up to the loss) in ONE launch: the above with the activations saved for
  * nerfhip_mlp_bwd_multi, and per pass what nerfhip_composite_train_fine_z / nerfhip_composite_train_loss append to the
  * quadrature — d MSE / d rgb, the compositing backward (g_raw_*), loss / PSNR / MSE (out3, reduced by the last workgroup to

@@ -71,6 +71,7 @@ SIGNATURES = {
     "nerfhip_mlp_pack_weights_train_multi": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                              ctypes.POINTER(_c_void_p), _int, _int, _c_void_p],
     "nerfhip_render_supported": [_i64, _int, _int, _int],
+    "nerfhip_render_test_fwd": [_c_void_p, _int, _c_void_p],
     "nerfhip_render_fwd": [_c_void_p, _int, _c_void_p],                  # (const nerfhip_render_args*: ctypes.addressof(RenderArgs))
     "nerfhip_render_train_fwd": [_c_void_p, _int, _c_void_p],
     "nerfhip_composite_train": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _f32, _int, _c_void_p, _f32, _c_void_p, _c_void_p,

@@ -38,10 +38,11 @@ V3_SCHED = os.environ.get("NERFHIP_V3_SCHED", "max-memory-clause")
 MULTI = {"mlp_fwd_variant.hip": [("_p%dm%dv%d" % (p, m, v), ["-DNH_PREC=%d" % p, "-DNH_MODE=%d" % m, "-DNH_VARIANT=%d" % v]
                                   + (["-mllvm", "-amdgpu-sched-strategy=" + V3_SCHED] if (v == 3 and V3_SCHED) else []))
                                  for p in (0, 1) for m in (0, 1) for v in (0, 1, 2, 3) if not (v == 3 and p == 0)],
-         # the single-launch render kernels: inference / training forward, per precision (e4m3 storage: bf16 only, same scheduling note)
+         # the single-launch render kernels: inference / training forward / test_time inference (sv 3), per precision (e4m3 storage:
+         # bf16 only, same scheduling note)
          "mlp_render_variant.hip": [("_p%ds%d" % (p, sv), ["-DNH_PREC=%d" % p, "-DNH_SV=%d" % sv]
                                      + (["-mllvm", "-amdgpu-sched-strategy=" + V3_SCHED] if (sv == 2 and V3_SCHED) else []))
-                                    for p in (0, 1) for sv in (0, 1, 2) if not (sv == 2 and p == 0)]}
+                                    for p in (0, 1) for sv in (0, 1, 2, 3) if not (sv == 2 and p == 0)]}
 
 
 # per-source extra flags.  The backward chain at its 256-register budget: hipcc's default strategy spills 30-56 VGPRs in the

@@ -215,6 +215,8 @@ __device__ __forceinline__ void composite_train_wave(const float* __restrict__ r
 }
 
 // the weights of one ray (the forward sweep above without the colours) into LDS: w_s[i] = alpha_i T_i, same expressions, same bits
+// (RAW_CH 4: raw = [r g b sigma] per point; 1: the sigma-only coarse pass of test_time, rendering.py:209-213)
+template <int RAW_CH = 4>
 __device__ __forceinline__ void composite_weights_wave(const float* __restrict__ raw, const float* __restrict__ z,
                                                        const float* __restrict__ rays, const float* __restrict__ noise,
                                                        float noise_std, int64_t r, int S, float* w_s, int lane) {
@@ -228,7 +230,7 @@ __device__ __forceinline__ void composite_weights_wave(const float* __restrict__
         if (valid) {
             zi = zr[i];
             zn = (i + 1 < S) ? zr[i + 1] : zi;
-            sigma = raw[(r * S + i) * 4 + 3];
+            sigma = RAW_CH == 4 ? raw[(r * S + i) * 4 + 3] : raw[r * S + i];
             if (noise) nz = nh_mul(noise[r * S + i], noise_std);
         }
         const SampleTerms t = sample_terms(zi, zn, i == S - 1, dnorm, sigma, nz);

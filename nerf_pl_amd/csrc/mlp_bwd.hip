@@ -139,6 +139,16 @@ static_assert(kDwFoldBiasCol < kDwMaxXTiles, "fold columns inside the slab");
 #define NERFHIP_DW_SPREAD 1      // bf16: the next stage's DMAs issued between the current stage's MFMAs (0 = in one block after the barrier)
 #endif
 
+#ifndef NERFHIP_DW_SPLIT2D
+#define NERFHIP_DW_SPLIT2D 1     // bf16, jobs with 8 dY tiles and 8 / 10 X tiles: wave = 2 dY tiles x (4 | 5) X tiles instead of 1 x (8 | 10) — 6 | 7
+#endif                           // operand fragments from LDS per k-step instead of 9 | 11 (round 6: profiles/r06_dw_bisect.txt, variant M)
+#ifndef NERFHIP_DW_RD2
+#define NERFHIP_DW_RD2 4         // ... its B fragments in flight
+#endif
+#ifndef NERFHIP_DW_BIAS_DOT2
+#define NERFHIP_DW_BIAS_DOT2 1   // bf16 bias partials by v_dot2_f32_bf16 against (1, 1), two chains, instead of 8 dependent cvt + add per fragment
+#endif
+
 #ifndef NERFHIP_DW_WGS
 #define NERFHIP_DW_WGS 512       // target workgroup count of the fp32 dW launch (2 rounds of 256 CUs at 1 workgroup/CU)
 #endif
@@ -166,6 +176,31 @@ template <int PREC> NH_HD constexpr int dw_depth(int pieces) {
     if (PREC != NERFHIP_BF16) return DwTraits<PREC>::DEPTH;
     const int d = DwTraits<PREC>::RING_BYTES / (pieces * kPieceBytes);
     return d > NERFHIP_DW_MAXDEPTH ? NERFHIP_DW_MAXDEPTH : d;
+}
+
+// One (dY tile, X tile) block of a workgroup's partial slab: 1024 floats, REGISTER-major since round 6 — float4 q of lane l at
+// float4 index 64 q + l, so that every store instruction of the epilogue writes 1 KiB contiguous (lane-major, a lane's 16 floats
+// together, made each of them 64 separate 16-byte pieces: profiles/r06_dw_bisect.txt, variants 7 -> F).  mlp_bwd_reduce_kernel
+// decodes the same order.
+__device__ __forceinline__ void dw_store_block(float* __restrict__ block, const f32x16& a, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        reinterpret_cast<float4*>(block)[64 * q + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+// sum of a bf16 A fragment's 8 values into two running fp32 partials (the bias gradient: dY summed over the points)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ void dw_bias_sum(const bf16x8& a, float& s0, float& s1) {
+#if NERFHIP_DW_BIAS_DOT2
+    const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[0], a[1]}, one, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[2], a[3]}, one, s1, false);
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[4], a[5]}, one, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[6], a[7]}, one, s1, false);
+#else
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0 += (float)a[j];
+#endif
 }
 
 template <int PREC>
@@ -224,10 +259,12 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
     float dbacc = 0.0f;
+    [[maybe_unused]] float dbacc2 = 0.0f;             // (second chain of the dot2 bias sums)
     [[maybe_unused]] f32x16 acc_sig;                  // (folded sigma head, class (8, 34) only)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_sig[r] = 0.0f;
     [[maybe_unused]] float dbacc_sig = 0.0f;
+    [[maybe_unused]] float dbacc_sig2 = 0.0f;
 
     // per-lane transposing-read geometry (bf16): 16-lane group g reads a [4 points][16 features] tile whose
     // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
@@ -254,6 +291,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         // class (8, 34) = the final layer with the sigma head folded in: stage = [dY_feat 16][h8 16][dY_sigma 2] slabs; every wave
         // adds ONE MFMA per k-step, dY_sigma x (X tile `wave`), into an accumulator of its own
         constexpr bool FOLD = NXT == 8 && NSL == 34;               // (bf16 since round 4, fp32 since round 5)
+        // round 6, bf16: the three classes with 8 dY tiles and 8 | 10 X tiles — (8, 32), (8, 34), (10, 36): 85 % of the launch's
+        // workgroups — give wave (wi = wave >> 1, wj = wave & 1) the dY tiles 2 wi, 2 wi + 1 against the X tiles XW wj .. XW wj + XW - 1
+        constexpr bool SPLIT2D = (PREC == NERFHIP_BF16) && NERFHIP_DW_SPLIT2D && (NXT == 8 || NXT == 10) && (NSL - 2 * NXT >= 16);
         constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
         constexpr int LPW = (NP + 7) / 8;
         constexpr int D = dw_depth<PREC>(NP);
@@ -327,7 +367,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #else
             wait_vm_barrier<(PREC == NERFHIP_BF16) ? (D - 2) * LPW : 0>();
 #endif
-            if (SPREAD && wave < n_ot) next_stage(it + D - 1);
+            if (SPREAD && (SPLIT2D || wave < n_ot)) next_stage(it + D - 1);
             else issue_stage(it + D - 1);
 #if NERFHIP_DW_PROBE
             const unsigned t3 = shader_cycles();
@@ -335,7 +375,70 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #endif
             const char* st_base = ring + s_use * STAGE;
             s_use = (s_use + 1 == D) ? 0 : s_use + 1;
-            if (wave < n_ot) {
+            if constexpr (SPLIT2D) {
+                constexpr int XW = NXT / 2, NF = 2 * XW, RD = NERFHIP_DW_RD2;
+                static_assert(RD >= 2 && RD <= NF, "B fragment ring");
+                const int wi = wave >> 1, wj = wave & 1;
+                const char* dyb = st_base + (4 * wi) * SLAB_BYTES;                       // dY tiles 2 wi, 2 wi + 1
+                const char* x_all = st_base + 16 * SLAB_BYTES;
+                const char* xb = x_all + (2 * XW * wj) * SLAB_BYTES;                    // X tiles XW wj ..
+                auto load_frag = [&](const char* pb, int q) {
+                    union { s16x4 h2[2]; bf16x8 v; } f;
+                    f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s0));
+                    f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s1));
+                    return f.v;
+                };
+                // piece k of the next stage is issued behind B step dma_after(k): the LPW DMAs spread evenly over the NF steps
+                auto dma_after = [](int k) constexpr { return ((k + 1) * NF) / LPW - 1; };
+                [[maybe_unused]] bf16x8 as0, as1, bs0, bs1;
+                if constexpr (FOLD) {                 // dY_sigma (slabs 32, 33 of the stage) against X tile 4 wj + wi: the 8 waves cover tiles 0..7
+                    const char* xs = x_all + 2 * (4 * wj + wi) * SLAB_BYTES;
+                    as0 = load_frag(st_base + 32 * SLAB_BYTES, 0);
+                    bs0 = load_frag(xs, 0);
+                    as1 = load_frag(st_base + 32 * SLAB_BYTES, 1);
+                    bs1 = load_frag(xs, 1);
+                }
+                bf16x8 a[2][2], b[RD];
+                a[0][0] = load_frag(dyb, 0);
+                a[0][1] = load_frag(dyb + 2 * SLAB_BYTES, 0);
+#pragma unroll
+                for (int f = 0; f < RD - 1; ++f) b[f] = load_frag(xb + 2 * (f % XW) * SLAB_BYTES, f / XW);
+                a[1][0] = load_frag(dyb, 1);
+                a[1][1] = load_frag(dyb + 2 * SLAB_BYTES, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {        // B step f = (k-step f / XW, X tile f % XW of this wave): two MFMAs
+                    if (f + RD - 1 < NF) b[(f + RD - 1) % RD] = load_frag(xb + 2 * ((f + RD - 1) % XW) * SLAB_BYTES, (f + RD - 1) / XW);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[2 * (f % XW)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f / XW][0], b[f % RD], acc[2 * (f % XW)], 0, 0, 0);
+                    acc[2 * (f % XW) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f / XW][1], b[f % RD], acc[2 * (f % XW) + 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (f == 0 || f == XW) {          // bias partial of dY tile 2 wi + wj (its two waves share the pair's two tiles)
+                        const bf16x8 ab = wj ? a[f / XW][1] : a[f / XW][0];
+                        dw_bias_sum(ab, dbacc, dbacc2);
+                    }
+                    if constexpr (FOLD) {
+                        if (f == 1) {
+                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as0, bs0, acc_sig, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            dw_bias_sum(as0, dbacc_sig, dbacc_sig2);
+                        }
+                        if (f == XW + 1) {
+                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as1, bs1, acc_sig, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            dw_bias_sum(as1, dbacc_sig, dbacc_sig2);
+                        }
+                    }
+                    if constexpr (SPREAD) {
+#pragma unroll
+                        for (int k = 0; k < LPW; ++k)
+                            if (dma_after(k) == f) {
+                                issue_piece(k);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                }
+            } else if (wave < n_ot) {
                 const char* dy_base = st_base + (2 * wave) * SLAB_BYTES;
                 const char* x_base = st_base + jb.dy_slabs * SLAB_BYTES;
                 if constexpr (PREC == NERFHIP_BF16) {
@@ -372,28 +475,20 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                         __builtin_amdgcn_sched_barrier(0);
                         acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m < NXT ? a0 : a1, b[m % RD], acc[x], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (m == 1) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) dbacc += (float)a0[j];
-                        }
+                        if (m == 1) dw_bias_sum(a0, dbacc, dbacc2);
                         if constexpr (FOLD) {
                             if (m == 3) {
                                 acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as0, bs0, acc_sig, 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) dbacc_sig += (float)as0[j];
+                                dw_bias_sum(as0, dbacc_sig, dbacc_sig2);
                             }
                             if (m == NXT + 3) {
                                 acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as1, bs1, acc_sig, 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) dbacc_sig += (float)as1[j];
+                                dw_bias_sum(as1, dbacc_sig, dbacc_sig2);
                             }
                         }
-                        if (m == NXT + 1 || (NXT == 1 && m == 1)) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) dbacc += (float)a1[j];
-                        }
+                        if (m == NXT + 1 || (NXT == 1 && m == 1)) dw_bias_sum(a1, dbacc, dbacc2);
                         if constexpr (SPREAD) {
                             if (m % DMA_STEP == DMA_STEP - 1 && m / DMA_STEP < LPW) {
                                 issue_piece(m / DMA_STEP);
@@ -430,22 +525,29 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the look-ahead DMAs before exit
-        // this workgroup's partial sums: [dY tile][X tile][lane][16] + one bias row per dY tile
+        // this workgroup's partial sums: [dY tile][X tile] blocks of 1024 floats (dw_store_block) + one bias row per dY tile
         float* sl = slabs + (size_t)blockIdx.x * kDwSlabFloats;
-        if (wave < n_ot) {
+        dbacc += dbacc2;
+        dbacc_sig += dbacc_sig2;
+        if constexpr (SPLIT2D) {
+            constexpr int XW = NXT / 2;
+            const int wi = wave >> 1, wj = wave & 1;
 #pragma unroll
-            for (int x = 0; x < NXT; ++x) {
-                float* dst = sl + ((size_t)(wave * kDwMaxXTiles + x) * 64 + lane) * 16;
+            for (int xl = 0; xl < XW; ++xl)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
+                for (int d = 0; d < 2; ++d)
+                    dw_store_block(sl + (size_t)((2 * wi + d) * kDwMaxXTiles + XW * wj + xl) * 1024, acc[2 * xl + d], lane);
+            sl[8 * kDwMaxXTiles * 64 * 16 + (2 * wi + wj) * 64 + lane] = dbacc;
+            if constexpr (FOLD) {                // the sigma head's (dY tile 0, X tile t = 4 wj + wi) partial: row t, column kDwFoldCol
+                dw_store_block(sl + (size_t)((4 * wj + wi) * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
+                if (wave == 0) sl[((size_t)(0 * kDwMaxXTiles + kDwFoldBiasCol) * 64) * 16 + lane] = dbacc_sig;
             }
+        } else if (wave < n_ot) {
+#pragma unroll
+            for (int x = 0; x < NXT; ++x) dw_store_block(sl + (size_t)(wave * kDwMaxXTiles + x) * 1024, acc[x], lane);
             sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
             if constexpr (FOLD) {                // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
-                float* dst = sl + ((size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 64 + lane) * 16;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc_sig[4 * q], acc_sig[4 * q + 1], acc_sig[4 * q + 2], acc_sig[4 * q + 3]);
+                dw_store_block(sl + (size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
                 if (wave == 0) sl[((size_t)(0 * kDwMaxXTiles + kDwFoldBiasCol) * 64) * 16 + lane] = dbacc_sig;
             }
         }
@@ -725,12 +827,7 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         float* slb = slabs + (size_t)blockIdx.x * kDwSlabFloats;
 #pragma unroll
         for (int x = 0; x < kDwMaxXTiles; ++x) {
-            if (x < n_xt) {
-                float* dst = slb + ((size_t)(wave * kDwMaxXTiles + x) * 64 + lane) * 16;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    reinterpret_cast<float4*>(dst)[q] = make_float4(acc[x][4 * q], acc[x][4 * q + 1], acc[x][4 * q + 2], acc[x][4 * q + 3]);
-            }
+            if (x < n_xt) dw_store_block(slb + (size_t)(wave * kDwMaxXTiles + x) * 1024, acc[x], lane);
         }
         // bias partials: every column of accb equals sum_p dY[p][row]; lanes 0 and 32 hold column 0 (rows 4H + (r&3) + 8(r>>2))
         if ((lane & 31) == 0) {
@@ -739,10 +836,7 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
         }
         if (fold) {                              // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
-            float* dst = slb + ((size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 64 + lane) * 16;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                reinterpret_cast<float4*>(dst)[q] = make_float4(acc_sig[4 * q], acc_sig[4 * q + 1], acc_sig[4 * q + 2], acc_sig[4 * q + 3]);
+            dw_store_block(slb + (size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
             if (wave == 0 && (lane & 31) == 0) {
                 float* bdst = slb + (size_t)kDwFoldBiasCol * 64 * 16;
 #pragma unroll
@@ -819,7 +913,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
             if (o < n_out) emit(G.b[jid] + o, sacc);
         }
     } else if (ot < n_ot && xt < n_xt) {
-        const int e4 = threadIdx.x;                    // floats 4*e4 .. 4*e4+3 of the tile: lane = e4>>2, r = 4*(e4&3)+k
+        const int e4 = threadIdx.x;                    // float4 e4 of the block (dw_store_block: register-major): lane = e4 & 63, r = 4*(e4>>6)+k
         const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
                                                             ((size_t)(fold >= 0 ? xt * kDwMaxXTiles + kDwFoldCol : ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -828,7 +922,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
             const float4 v = src[(size_t)sp * (kDwSlabFloats / 4)];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        const int lane = e4 >> 2, rq = e4 & 3;
+        const int lane = e4 & 63, rq = e4 >> 6;
         const int h = lane >> 5, ncol = lane & 31;
         const int m0 = 8 * rq + 4 * h;                     // operand rows m0 .. m0+3  (reg r = 4*rq + k -> (r&3) = k, r>>2 = rq)
         // natural order: row m = feature 32 ot + m.  F8: m -> feature chain_feature(m >> 4, (m >> 3) & 1, m & 7) of the tile

@@ -14,6 +14,8 @@ template <> int launch_render_variant<NERFHIP_F32, 1>(const RenderArgs&, unsigne
 template <> int launch_render_variant<NERFHIP_BF16, 0>(const RenderArgs&, unsigned, hipStream_t);
 template <> int launch_render_variant<NERFHIP_BF16, 1>(const RenderArgs&, unsigned, hipStream_t);
 template <> int launch_render_variant<NERFHIP_BF16, 2>(const RenderArgs&, unsigned, hipStream_t);
+template <> int launch_render_variant<NERFHIP_F32, 3>(const RenderArgs&, unsigned, hipStream_t);
+template <> int launch_render_variant<NERFHIP_BF16, 3>(const RenderArgs&, unsigned, hipStream_t);
 
 static int render_tail_floats_host(int S_c, int N_i) {
     const int S_f = S_c + N_i;
@@ -65,6 +67,17 @@ extern "C" int nerfhip_render_fwd(const nerfhip_render_args* args, int dtype, ne
     const unsigned groups = (unsigned)(args->B / kRenderRays);
     if (dtype == NERFHIP_F32) return launch_render_variant<NERFHIP_F32, 0>(*args, groups, (hipStream_t)stream);
     return launch_render_variant<NERFHIP_BF16, 0>(*args, groups, (hipStream_t)stream);
+}
+
+extern "C" int nerfhip_render_test_fwd(const nerfhip_render_args* args, int dtype, nerfhip_stream_t stream) {
+    using namespace nerfhip;
+    if (args && args->B == 0) return 0;
+    const int rc = render_check(args, dtype, false);
+    if (rc) return rc;
+    NERFHIP_CHECK_ARG(args->N_i > 0);          // test_time without a fine pass returns nothing but an opacity: not this kernel's business
+    const unsigned groups = (unsigned)(args->B / kRenderRays);
+    if (dtype == NERFHIP_F32) return launch_render_variant<NERFHIP_F32, 3>(*args, groups, (hipStream_t)stream);
+    return launch_render_variant<NERFHIP_BF16, 3>(*args, groups, (hipStream_t)stream);
 }
 
 extern "C" int nerfhip_render_train_fwd(const nerfhip_render_args* args, int dtype, nerfhip_stream_t stream) {

@@ -13,6 +13,9 @@
 // bits, as the stand-alone launches.  The grid is B / 4 workgroups: 256 for the 1024-ray training batch, one per CU.
 // Tile numbering of the saved activations is that of the stand-alone forward launches (a group's points are consecutive in
 // the flat (B, S) order), so the backward kernels do not know which forward produced their operands.
+// SV (the variant): 0 inference | 1 training forward, activations saved in the compute precision | 2 the same with block-scaled e4m3
+// copies | 3 inference under test_time (rendering.py:209-213, eval.py:69-79): the COARSE sub-passes run the network's sigma-only
+// body (nerf.py:112-114: it stops at the density head), raw_coarse is (B, S_c), only opacity_coarse leaves the coarse pass.
 #pragma once
 #include "composite_wave.h"
 #include "mlp_fwd_kernel.h"
@@ -50,7 +53,7 @@ __device__ __forceinline__ RenderArgsP render_args() {
 
 // compositing of the group's rays in one pass (+ the fine depths, after the coarse pass): R or 2 R one-wave jobs shared out over
 // the workgroup's waves; `tail_lds`: the weight ring, idle between sub-passes
-template <bool TRAIN, int NW>
+template <bool TRAIN, int NW, bool TT = false>
 __device__ __forceinline__ void render_tail(const bool fine_pass, const bool with_fine_z, float* const tail_lds, const int wave,
                                             const int lane) {
     constexpr int R = kRenderRays;
@@ -79,13 +82,15 @@ __device__ __forceinline__ void render_tail(const bool fine_pass, const bool wit
             if constexpr (TRAIN) {
                 composite_train_wave<true>(raw, z, rays, noise, noise_std, white_back, a->target, a->grad_scale, nullptr, rgb, depth, opac,
                                            fine_pass ? a->g_raw_fine : a->g_raw_coarse, r, S, base, nullptr, lane);
+            } else if (TT && !fine_pass) {       // test_time: the coarse pass keeps its opacity only   rendering.py:209-213
+                composite_fwd_wave<1>(raw, z, rays, noise, noise_std, white_back, nullptr, nullptr, nullptr, opac, r, S, nullptr, lane);
             } else {
                 composite_fwd_wave<4>(raw, z, rays, noise, noise_std, white_back, nullptr, rgb, depth, opac, r, S, nullptr, lane);
             }
         } else {
             // the same ray's weights again (forward sweep only: raw is in L2) and the fine depths from them   rendering.py:223-229
             float* w_s = base + S4;
-            composite_weights_wave(raw, z, rays, noise, noise_std, r, S, w_s, lane);
+            composite_weights_wave<(TT ? 1 : 4)>(raw, z, rays, noise, noise_std, r, S, w_s, lane);
             __builtin_amdgcn_wave_barrier();
             const float* u = a->u;
             fine_z_wave(w_s + S4, z + r * S, [&](int j) { return w_s[1 + j]; }, u ? u + r * a->u_stride : nullptr, S, N_i, a->eps,
@@ -95,9 +100,10 @@ __device__ __forceinline__ void render_tail(const bool fine_pass, const bool wit
 }
 
 template <int PREC, int SV>
-__global__ __launch_bounds__((KCfg<PREC, (SV != 0)>::NW * 64), (KCfg<PREC, (SV != 0)>::WPS))
+__global__ __launch_bounds__((KCfg<PREC, (SV == 1 || SV == 2)>::NW * 64), (KCfg<PREC, (SV == 1 || SV == 2)>::WPS))
 void mlp_render_kernel(const RenderArgs args_by_value) {          // (read through render_args(), never by name)
-    constexpr bool TRAIN = SV != 0;
+    constexpr bool TRAIN = SV == 1 || SV == 2, TT = SV == 3;
+    constexpr int FSV = TT ? 0 : SV;                               // the network body's own variant
     constexpr int NW = KCfg<PREC, TRAIN>::NW, PTS = 32 * NW, R = kRenderRays;
     __shared__ __attribute__((aligned(1024))) char lds_all[FwdLds<PREC, TRAIN>::kBytes];
     __shared__ float red[2][16];
@@ -117,7 +123,7 @@ void mlp_render_kernel(const RenderArgs args_by_value) {          // (read throu
     for (int sp = 0; sp < total; ++sp) {
         if (sp > 0) render_wg_sync();
         if (sp == nc) {                   // (only with a fine pass) the coarse pass is complete for this group's rays
-            render_tail<TRAIN, NW>(false, true, tail_lds, wave, lane);
+            render_tail<TRAIN, NW, TT>(false, true, tail_lds, wave, lane);
             render_wg_sync();
         }
         const RenderArgsP a = render_args();
@@ -127,11 +133,15 @@ void mlp_render_kernel(const RenderArgs args_by_value) {          // (read throu
         const FwdZGen zg{fine ? nullptr : a->perturb_rand, fine ? nullptr : a->z_coarse, fine ? 0 : a->use_disp, fine ? 0.0f : a->perturb};
         uint8_t* save = nullptr;
         if constexpr (TRAIN) save = (uint8_t*)(fine ? a->save_fine : a->save_coarse);
-        mlp_fwd_body<PREC, MODE_RAYS, false, SV>(lds_all, blk, a->rays, fine ? a->z_fine : nullptr, a->B * (int64_t)S, (int64_t)S,
-                                                 (const uint8_t*)(fine ? a->packed_fine : a->packed_coarse), fine ? a->raw_fine : a->raw_coarse, save, zg);
+        if (TT && !fine)                  // (wave-uniform) the coarse network up to the density head: out = sigma (B, S_c)
+            mlp_fwd_body<PREC, MODE_RAYS, true, 0>(lds_all, blk, a->rays, nullptr, a->B * (int64_t)S, (int64_t)S, (const uint8_t*)a->packed_coarse,
+                                                   a->raw_coarse, nullptr, zg);
+        else
+            mlp_fwd_body<PREC, MODE_RAYS, false, FSV>(lds_all, blk, a->rays, fine ? a->z_fine : nullptr, a->B * (int64_t)S, (int64_t)S,
+                                                      (const uint8_t*)(fine ? a->packed_fine : a->packed_coarse), fine ? a->raw_fine : a->raw_coarse, save, zg);
     }
     render_wg_sync();
-    render_tail<TRAIN, NW>(nf > 0, false, tail_lds, wave, lane);
+    render_tail<TRAIN, NW, TT>(nf > 0, false, tail_lds, wave, lane);
 
     if constexpr (TRAIN) {
         // loss / PSNR values (mse_psnr_kernel's own order, loss_math.h): every workgroup announces its rays' colours — device-scope

@@ -36,7 +36,16 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
 def _render_test_time(models, rays, N_samples, N_importance, use_disp, white_back):
     """The test_time launch sequence of render_rays without the (unused, noise_std=0) RNG draws:
     sample_coarse_z -> mlp(coarse, sigma only) -> composite -> fine_z -> mlp(fine) -> composite.
-    Allocation-free apart from torch.empty outputs => capturable."""
+    Allocation-free apart from torch.empty outputs => capturable.
+    Where the single-launch kernel takes the shape (nerfhip_render_test_fwd: sigma-only coarse sub-passes, round 6) the whole
+    sequence is that ONE launch — the same bits (tests/test_gpu_render_fused.py)."""
+    from .models import rendering as R
+    dtype = models[0].mlp_dtype
+    if (R.FUSE_TEST_TIME and N_importance > 0 and models[1].mlp_dtype == dtype
+            and ops.render_supported(rays.shape[0], N_samples, N_importance, dtype)):
+        o = ops.render_fwd(rays, N_samples, N_importance, models[0].packed_weights(), models[1].packed_weights(), dtype, use_disp, 0.0, None,
+                           None, None, 0.0, white_back, None, want_coarse=False, test_time=True)
+        return {k: o[k] for k in ("opacity_coarse", "rgb_fine", "depth_fine", "opacity_fine")}
     z = ops.sample_coarse_z(rays, N_samples, use_disp, 0.0, None)
     sig = ops.mlp_fwd_rays(rays, z, models[0].packed_weights(), True, models[0].mlp_dtype)
     w, opac_c = ops.composite(sig, z, rays, None, 0.0, white_back)

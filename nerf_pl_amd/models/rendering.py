@@ -18,10 +18,11 @@ from .. import draws as D
 from .. import ops
 from .mlp_autograd import _needs_grad, mlp_rays
 
-# test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too?  It evaluates
-# the FULL coarse network (same sigma, 21 % more coarse FLOPs = 4 % of the call) and saves four launches per chunk; measured on
-# MI355X (profiles/README.md, round 5) — the setting below is the faster one for 32768-ray chunks.
-FUSE_TEST_TIME = os.environ.get("NERFHIP_FUSE_TEST_TIME", "0") == "1"
+# test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too: since round 6 its
+# coarse sub-passes run the network's sigma-only body (nerfhip_render_test_fwd), so the launch does exactly the FLOPs of the five
+# launches it replaces (round 5's form evaluated the full coarse network: +21 % coarse FLOPs, and lost to the launches).
+# NERFHIP_FUSE_TEST_TIME=0 keeps the launches (A/B; bit-identical results either way: tests/test_gpu_render_fused.py).
+FUSE_TEST_TIME = os.environ.get("NERFHIP_FUSE_TEST_TIME", "1") == "1"
 
 __all__ = ['render_rays']
 
@@ -104,7 +105,8 @@ def render_rays(models,
     # groups: the same four draws in the same order first, then workgroups that own 4 rays each run coarse MLP -> compositing ->
     # fine depths -> fine MLP -> compositing (csrc/mlp_render_kernel.h; bit-identical to the launches below)
     if (dev.type == "cuda" and _fusable(models, embeddings) and not (torch.is_grad_enabled() and any(_needs_grad(m) for m in models[:2]))
-            and (N_importance == 0 or models[0].mlp_dtype == models[1].mlp_dtype) and (FUSE_TEST_TIME or not test_time)
+            and (N_importance == 0 or models[0].mlp_dtype == models[1].mlp_dtype)
+            and (not test_time or (FUSE_TEST_TIME and N_importance > 0))
             and ops.render_supported(N_rays, N_samples, N_importance, model_coarse.mlp_dtype)):
         graph_rng = D.in_graph_stream(dev)
         rnd = (lambda *sh: D.rand(sh, dev)) if graph_rng else (lambda *sh: torch.rand(*sh, device=dev))
@@ -118,7 +120,7 @@ def render_rays(models,
         dtype = model_coarse.mlp_dtype
         out = ops.render_fwd(rays, N_samples, N_importance, model_coarse.packed_weights(dtype),
                              models[1].packed_weights(dtype) if N_importance > 0 else None, dtype, use_disp, perturb, perturb_rand,
-                             noise_c, noise_f, noise_std, white_back, u, want_coarse=not test_time)
+                             noise_c, noise_f, noise_std, white_back, u, want_coarse=not test_time, test_time=test_time)
         result = {'opacity_coarse': out['opacity_coarse']} if test_time else \
             {'rgb_coarse': out['rgb_coarse'], 'depth_coarse': out['depth_coarse'], 'opacity_coarse': out['opacity_coarse']}
         if N_importance > 0:

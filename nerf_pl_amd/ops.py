@@ -554,12 +554,13 @@ def render_supported(B, S_c, N_i, dtype):
 
 
 def _render_args(rays, S, N, packed_c, packed_f, use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u, eps,
-                 want_coarse):
+                 want_coarse, coarse_sigma_only=False):
     B = rays.shape[0]
     dev = rays.device
     f32 = dict(device=dev, dtype=torch.float32)
     a = _lib.RenderArgs()
-    bufs = {"z_coarse": torch.empty(B, S, **f32), "raw_coarse": torch.empty(B, S, 4, **f32), "opacity_coarse": torch.empty(B, **f32)}
+    bufs = {"z_coarse": torch.empty(B, S, **f32), "opacity_coarse": torch.empty(B, **f32),
+            "raw_coarse": torch.empty((B, S) if coarse_sigma_only else (B, S, 4), **f32)}
     if want_coarse:
         bufs.update(rgb_coarse=torch.empty(B, 3, **f32), depth_coarse=torch.empty(B, **f32))
     if N > 0:
@@ -600,14 +601,20 @@ def _render_args(rays, S, N, packed_c, packed_f, use_disp, perturb, perturb_rand
 
 @device_guard
 def render_fwd(rays, n_samples, n_importance, packed_coarse, packed_fine, dtype, use_disp=False, perturb=0.0, perturb_rand=None,
-               noise_coarse=None, noise_fine=None, noise_std=0.0, white_back=False, u=None, eps=1e-5, want_coarse=True):
+               noise_coarse=None, noise_fine=None, noise_std=0.0, white_back=False, u=None, eps=1e-5, want_coarse=True, test_time=False):
     """render_rays (rendering.py:58-244) for one ray chunk in ONE launch (nerfhip_render_fwd).  Returns the dict of every buffer
-    the launch wrote: rgb / depth / opacity of both passes (rgb_coarse / depth_coarse only with want_coarse), z_* and raw_*."""
+    the launch wrote: rgb / depth / opacity of both passes (rgb_coarse / depth_coarse only with want_coarse), z_* and raw_*.
+    test_time (rendering.py:209-213, N_importance > 0): nerfhip_render_test_fwd — the coarse sub-passes run the network's sigma-only
+    body, raw_coarse is (B, S) and the coarse pass leaves opacity_coarse only."""
     require_gpu(rays, perturb_rand, noise_coarse, noise_fine, u)
     rays = _c(rays)
+    tt = bool(test_time) and int(n_importance) > 0
     a, bufs, keep = _render_args(rays, n_samples, n_importance, packed_coarse, packed_fine, use_disp, perturb, perturb_rand,
-                                 noise_coarse, noise_fine, noise_std, white_back, u, eps, want_coarse)
-    check(_lib.load().nerfhip_render_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_fwd")
+                                 noise_coarse, noise_fine, noise_std, white_back, u, eps, want_coarse and not tt, coarse_sigma_only=tt)
+    if tt:
+        check(_lib.load().nerfhip_render_test_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_test_fwd")
+    else:
+        check(_lib.load().nerfhip_render_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_fwd")
     return bufs
 
 

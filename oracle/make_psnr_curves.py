@@ -51,6 +51,10 @@ def batch_indices(perm, step, n_rays):
     return perm[((step - 1) * B) % (n_rays - B):][:B]
 
 
+DEAD_AT, DEAD_BELOW_DB = 100, 9.0     # a run still at the all-white solution's PSNR (7.7 dB on this scene) at step 100 stays there (the dead-ReLU
+                                       # density head every NeRF implementation knows): recorded as dead and cut short — no signal in it
+
+
 def train_reference(seed, steps, checks, data, log=print):
     nerf, rend, _calls, replay = build_reference()
     losses_mod = ref_shim._load("_ref_losses", "losses.py")
@@ -85,7 +89,10 @@ def train_reference(seed, steps, checks, data, log=print):
                 assert not replay.queue
             curve[step] = O.psnr(img, rgb_val).item()
             log("seed %d step %d: loss %.5f  held-out PSNR %.3f dB  (%.0f s)" % (seed, step, losses[-1], curve[step], time.time() - t0))
-    return {"seed": seed, "init_digest": digest, "psnr": curve, "loss": losses}
+            if step == DEAD_AT and curve[step] < DEAD_BELOW_DB:
+                log("seed %d: dead init (%.2f dB at step %d), cut short" % (seed, curve[step], step))
+                return {"seed": seed, "init_digest": digest, "dead": True, "psnr": curve, "loss": losses}
+    return {"seed": seed, "init_digest": digest, "dead": False, "psnr": curve, "loss": losses}
 
 
 def main():
@@ -97,10 +104,11 @@ def main():
     ap.add_argument("--from-step", type=int, default=50)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default=OUT)
+    ap.add_argument("--merge", nargs="*", default=[], help="other output files of this script (same settings) whose runs are merged into --out")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     data = brick_scene(N_TRAIN_RAYS, 1, "cpu") + brick_scene(N_VAL_RAYS, 2, "cpu")
-    checks = set(range(a.from_step, a.steps + 1, a.every))
+    checks = set(range(a.from_step, a.steps + 1, a.every)) | {DEAD_AT}
     doc = {"what": "held-out PSNR@step of the REAL reference (unmodified models/nerf.py, models/rendering.py, losses.py; "
                    "torch-CPU fp32 autograd + torch.optim.Adam lr 5e-4 eps 1e-8) trained by oracle/make_psnr_curves.py",
            "torch": torch.__version__, "B": B, "S": S, "N": N, "steps": a.steps, "n_train_rays": N_TRAIN_RAYS, "n_val_rays": N_VAL_RAYS,
@@ -111,6 +119,12 @@ def main():
             old = json.load(fh)
         if all(old.get(k) == doc[k] for k in ("B", "S", "N", "steps", "n_train_rays", "n_val_rays")):
             doc["runs"] = old["runs"]
+    for other in a.merge:
+        with open(other) as fh:
+            o = json.load(fh)
+        assert all(o.get(k) == doc[k] for k in ("B", "S", "N", "steps", "n_train_rays", "n_val_rays")), other
+        doc["runs"] += [r for r in o["runs"] if r["seed"] not in {x["seed"] for x in doc["runs"]}]
+        doc["runs"].sort(key=lambda r: r["seed"])
     have = {r["seed"] for r in doc["runs"]}
     for seed in range(a.first_seed, a.first_seed + a.seeds):
         if seed in have:

@@ -14,6 +14,7 @@ from tests.helpers import build_models, case_from_golden, hip_render
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-4, 1e-4
+GOLDEN_ATOL = 1e-5                 # absolute floor of the golden render_rays comparisons (depths are O(1..6), colours O(0.01..1))
 
 
 def test_posenc_vs_reference_golden(golden, dev):
@@ -362,31 +363,74 @@ def test_render_rays_fp32_vs_reference_golden(golden, dev):
             ref = golden[f"rr_{name}_{k}"]
             got = res[k].cpu()
             assert got.shape == ref.shape
-            assert torch.allclose(got, ref, rtol=RTOL, atol=ATOL), (name, k, (got - ref).abs().max().item())
+            # relative 1e-4 with an absolute floor of 1e-5 (round 6; was 1e-4: 1 % of a colour of 0.01).  Measured per key over the
+            # nine reference-minted cases: profiles/r06_parity_errors.txt
+            err, rel = (got - ref).abs().max().item(), ((got - ref).abs() / ref.abs().clamp(min=1e-3)).max().item()
+            print("golden %-18s %-15s max |diff| %.2e  max rel (floor 1e-3) %.2e" % (name, k, err, rel))
+            assert torch.allclose(got, ref, rtol=RTOL, atol=GOLDEN_ATOL), (name, k, err, rel)
 
 
 def test_render_rays_fp32_benchmark_size_vs_oracle(dev):
     """BASELINE configs[2] size on the GPU box: 1024 rays x (64 + 128) samples, fp32 MFMA path against the pinned CPU
-    oracle (one oracle forward at this size costs ~1 s of CPU), perturb=1, noise_std=1, replayed RNG draws."""
+    oracle (one oracle forward at this size costs ~1 s of CPU), perturb=1, noise_std=1, replayed RNG draws.
+
+    Per-ray accounting instead of an error budget.  `sample_pdf` is DISCONTINUOUS in its weights — the
+    searchsorted index (rendering.py:42) and the `denom < eps -> 1` switch (:51) flip on the last bit of the cdf — so two correct
+    implementations whose coarse weights differ by rounding can place a few importance samples elsewhere inside a bin, and those
+    rays then differ by more than 1e-4.  The test therefore proves, for EVERY ray:
+      (1) coarse pass: depths bit-equal, weights within 2e-6 of the oracle's (the inputs of sample_pdf differ in their last bits only);
+      (2) the HIP path's fine samples ARE the reference algorithm's answer on the HIP path's own weights: the oracle's sample_pdf,
+          fed those weights and the same u, returns them (<= 1 ulp of the depth range);
+      (3) a ray is a `moved` ray iff the oracle's samples on ITS OWN weights differ from (2)'s by more than 1e-5; every output
+          element outside the 1e-4 tolerance belongs to a moved ray, and moved rays are rare (<= 1 %; measured 0-3 of 1024);
+      (4) on all other rays every output holds rtol 1e-4 with an absolute floor of 1e-5."""
+    from nerf_pl_amd import ops
     B, S, N = 1024, 64, 128
     params = [O.make_params(31, 4.0, 0.2), O.make_params(32, 4.0, 0.2)]
     rays = O.make_rays(77, B, "blender")
     rng = O.draw_rng(5, B, S, N, 1.0)
-    kw = dict(N_samples=S, use_disp=False, perturb=1.0, noise_std=1.0, N_importance=N, white_back=True, test_time=False)
-    ref = O.render_rays(params, rays, S, False, 1.0, 1.0, N, True, False, rng=rng)
+    ref, aux = O.render_rays(params, rays, S, False, 1.0, 1.0, N, True, False, rng=rng, return_aux=True)
     ms, emb = build_models(params, dev, "fp32")
+    r_d = rays.to(dev)
+    d = {k: v.to(dev) for k, v in rng.items()}
     with torch.no_grad():
-        res = hip_render(ms, emb, rays, kw, rng, dev)
-    assert sorted(res.keys()) == sorted(ref.keys())
+        # render_rays under no_grad IS this launch (tests/test_gpu_render_fused.py); called directly it also hands back its intermediates
+        got = ops.render_fwd(r_d, S, N, ms[0].packed_weights("fp32"), ms[1].packed_weights("fp32"), "fp32", False, 1.0, d["perturb_rand"],
+                             d["noise_coarse"], d["noise_fine"], 1.0, True, d["u"])
+        w_c = ops.composite(got["raw_coarse"], got["z_coarse"], r_d, d["noise_coarse"], 1.0, True)[0]
+        res = hip_render(ms, emb, rays, dict(N_samples=S, use_disp=False, perturb=1.0, noise_std=1.0, N_importance=N, white_back=True,
+                                             test_time=False), rng, dev)
+    for k in ref:                                                      # the public entry point returns the launch's outputs
+        assert torch.equal(res[k], got[k]), k
+    z_c, z_f, w_c = got["z_coarse"].cpu(), got["z_fine"].cpu(), w_c.cpu()
+    # (1)
+    assert torch.equal(z_c, aux["z_coarse"])
+    werr = (w_c - aux["weights_coarse"]).abs().max().item()
+    assert werr <= 2e-6, werr
+    # (2) the new samples of the HIP path = its sorted fine depths minus the coarse depths (both bit-exact multisets)
+    mid = 0.5 * (z_c[:, :-1] + z_c[:, 1:])
+    total = "torch" if ops._row_total == ops._ROW_TOTAL_MODES["aten"] else "exact"         # the rounding of the row total the launch used
+    new_on_hip_w = torch.sort(O.sample_pdf(mid, w_c[:, 1:-1], N, u=rng["u"], total=total), -1)[0]
+    merged = torch.sort(torch.cat([z_c, new_on_hip_w], -1), -1)[0]
+    zerr = (merged - z_f).abs().max().item()
+    assert zerr <= 5e-7, zerr
+    # (3)
+    new_ref = torch.sort(aux["z_new"], -1)[0]
+    moved = (new_on_hip_w - new_ref).abs().amax(1) > 1e-5
+    n_moved = int(moved.sum())
+    assert n_moved <= B // 100, n_moved
     for k in ref:
-        got = res[k].cpu()
-        assert got.shape == ref[k].shape
-        # importance samples that land on the other side of a coarse sample (the coarse weights of the fp32 MFMA path and of
-        # ATen's GEMMs differ in their last bits, hence so do the cdfs) meet ANOTHER noise draw of the (B, S_f) noise tensor and
-        # change single rays by more than 1e-4: at most a handful of the 1024 rays may do so (measured 0-3, whichever rounding
-        # the row total uses), the rest hold the 1e-4 bound
-        bad = ~torch.isclose(got, ref[k], rtol=RTOL, atol=ATOL)
-        frac = bad.float().mean().item()
-        assert frac <= 5e-3, (k, frac, (got - ref[k]).abs().max().item())
-        print("render_rays 1024x(64+128) fp32 vs oracle: %s max |diff| %.2e, outside 1e-4: %d of %d"
-              % (k, (got - ref[k]).abs().max().item(), int(bad.sum()), bad.numel()))
+        g, r = got[k].cpu(), ref[k]
+        assert g.shape == r.shape
+        bad = ~torch.isclose(g, r, rtol=RTOL, atol=ATOL)
+        bad_rays = bad.reshape(B, -1).any(1)
+        assert not (bad_rays & ~moved).any(), (k, "an out-of-tolerance ray whose importance samples did not move",
+                                               torch.nonzero(bad_rays & ~moved).flatten().tolist())
+        # (4)
+        keep = ~moved
+        rel = ((g - r).abs() / r.abs().clamp(min=1e-3)).reshape(B, -1)[keep]
+        assert torch.allclose(g.reshape(B, -1)[keep], r.reshape(B, -1)[keep], rtol=RTOL, atol=1e-5), (k, (g - r).abs().reshape(B, -1)[keep].max().item())
+        print("render_rays 1024x(64+128) fp32 vs oracle: %s max |diff| %.2e, max rel (floor 1e-3) %.2e on the %d rays whose samples did not move; "
+              "%d moved ray(s), of which %d outside 1e-4" % (k, (g - r).abs().reshape(B, -1)[keep].max().item(), rel.max().item(), int(keep.sum()),
+                                                             n_moved, int((bad_rays & moved).sum())))
+    print("coarse weights max |diff| %.2e; fine depths vs oracle.sample_pdf on the HIP weights max |diff| %.2e" % (werr, zerr))

@@ -229,7 +229,7 @@ def reference_paired_statistics(dev, dtypes=("fp32", "bf16"), row_total=None, ma
     ref_end = []
     for run in doc["runs"][:max_seeds]:
         ref = {int(k): v for k, v in run["psnr"].items()}
-        if ref[doc["steps"]] < REF_DEAD_BELOW_DB:
+        if run.get("dead") or ref[doc["steps"]] < REF_DEAD_BELOW_DB:
             out["dead_seeds"].append(run["seed"])
             continue
         out["seeds"].append(run["seed"])

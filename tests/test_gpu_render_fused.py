@@ -71,6 +71,56 @@ def test_render_fwd_is_the_launches_it_replaces(dev, dtype, B, S, N, perturb, us
         assert torch.equal(got2["rgb_fine"], want["rgb_fine"])
 
 
+@pytest.mark.parametrize("dtype,B,S,N,perturb,use_disp,noise_std,white_back,rand_u,kind", [c for c in CASES if c[3] > 0] + [
+    ("bf16", 32768, 64, 128, 0.0, False, 0.0, True, False, "blender"),       # eval.py's chunk (eval.py:65), its flags (:69-79)
+    ("fp32", 2048, 64, 128, 0.0, False, 0.0, True, False, "blender")])
+def test_render_test_fwd_is_the_five_launches_of_test_time(dev, dtype, B, S, N, perturb, use_disp, noise_std, white_back, rand_u, kind):
+    """test_time (rendering.py:209-213: the coarse model answers sigma_only, nerf.py:112-114) in ONE launch — nerfhip_render_test_fwd,
+    whose coarse sub-passes run the network's sigma-only body — against the five launches render_rays issued for it until round 5,
+    bit for bit: coarse depths, coarse sigma (B,S), coarse opacity, fine depths, fine rgb sigma, fine outputs."""
+    from nerf_pl_amd import ops
+    ms, _ = _models(dev, dtype)
+    rays = O.make_rays(4, B, kind).to(dev)
+    d = _draws(B, S, N, dev, seed=1)
+    pr = d["perturb_rand"] if perturb > 0 else None
+    u = d["u"] if rand_u else None
+    pc, pf = ms[0].packed_weights(dtype), ms[1].packed_weights(dtype)
+    z, sig_c = ops.mlp_fwd_rays_coarse(rays, S, pc, True, dtype, use_disp, perturb, pr)
+    w_c, opac_c = ops.composite(sig_c, z, rays, d["noise_coarse"], noise_std, white_back)
+    zf = ops.fine_z(z, w_c, N, u=u)
+    raw_f = ops.mlp_fwd_rays(rays, zf, pf, False, dtype)
+    _, opac_f, rgb_f, depth_f = ops.composite(raw_f, zf, rays, d["noise_fine"], noise_std, white_back)
+    want = {"z_coarse": z, "raw_coarse": sig_c, "opacity_coarse": opac_c, "z_fine": zf, "raw_fine": raw_f, "rgb_fine": rgb_f,
+            "depth_fine": depth_f, "opacity_fine": opac_f}
+    got = ops.render_fwd(rays, S, N, pc, pf, dtype, use_disp, perturb, pr, d["noise_coarse"], d["noise_fine"], noise_std, white_back, u,
+                         want_coarse=False, test_time=True)
+    torch.cuda.synchronize()
+    assert set(got) == set(want) and tuple(got["raw_coarse"].shape) == (B, S)
+    for k in want:
+        assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+
+
+def test_graph_renderer_single_launch_equals_its_launches(dev):
+    """inference.GraphRenderer (eval.py's chunk loop as hipGraph replays): the captured chunk is ONE launch since round 6; same pixels
+    as the captured five launches, ragged tail included."""
+    from nerf_pl_amd.inference import GraphRenderer
+    from nerf_pl_amd.models import rendering
+    ms, emb = _models(dev, "bf16")
+    rays = O.make_rays(21, 32768 + 1000, "blender").to(dev)
+    out = {}
+    prev = rendering.FUSE_TEST_TIME
+    try:
+        for on in (False, True):
+            rendering.FUSE_TEST_TIME = on
+            gr = GraphRenderer(ms, emb, 64, 128, False, True)
+            out[on] = gr.render_to_host(rays, keys=("rgb_fine", "depth_fine"))
+            torch.cuda.synchronize()
+    finally:
+        rendering.FUSE_TEST_TIME = prev
+    for k in out[False]:
+        assert torch.equal(out[False][k], out[True][k]), k
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("test_time", [False, True])
 def test_render_rays_takes_the_single_launch_and_returns_the_same(dev, dtype, test_time):
