@@ -201,6 +201,10 @@ NH_HD constexpr int act_tile_bytes(int prec) { return act_mask_off(prec) + kMask
 #ifndef NERFHIP_ACT_IL
 #define NERFHIP_ACT_IL 1
 #endif
+// The saved-tensor buffers are sized in whole bf16 workgroups = 8 wave tiles (nerfhip_mlp_act_bytes / _dy_bytes): an interleave group
+// must divide that, or the last group of a buffer would be addressed past its end.
+static_assert(NERFHIP_ACT_IL == 1 || NERFHIP_ACT_IL == 2 || NERFHIP_ACT_IL == 4 || NERFHIP_ACT_IL == 8,
+              "NERFHIP_ACT_IL must divide the 8 wave tiles the bf16 buffers are padded to");
 NH_HD constexpr int act_il(int prec, bool f8 = false) { return (prec == 1 /*NERFHIP_BF16*/ && !f8) ? NERFHIP_ACT_IL : 1; }
 // byte offset of piece 0 of wave tile `tile` in a buffer of blocks of `tile_bytes`; its piece p follows at p * il KiB
 NH_HD inline size_t tile_block_off(long long tile, int tile_bytes, int il) {

@@ -157,6 +157,10 @@ void mlp_render_kernel(const RenderArgs args_by_value) {          // (read throu
         }
         __syncthreads();
         if (!last_s) return;
+        // consumer side of the hand-off: an agent-scope ACQUIRE in the one workgroup that reads the others' colours.  The
+        // producer side stays write-through stores + s_waitcnt vmcnt(0) + the relaxed ticket: an agent-scope RELEASE there writes this
+        // XCD's whole L2 back once per workgroup (measured: 20 us per launch instead of 7, round 4).
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const float* img_c = a->rgb_coarse;
         const float* img_f = a->rgb_fine;
         const float* target = a->target;

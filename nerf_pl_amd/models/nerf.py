@@ -75,6 +75,11 @@ class NeRF(nn.Module):
         self.mlp_dtype = default_mlp_dtype()    # 'fp32' (parity) | 'bf16' | 'bf16_f8' (roofline); a non-default shape runs
                                                 # layer by layer (models/layered.py) and reads 'bf16_f8' as 'bf16'
         self._packed_cache = {}
+        # weights replaced wholesale (load_ckpt, utils/__init__.py:55-76): weight images packed ahead of a step are stale
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module._bump_weights_serial())
+
+    def _bump_weights_serial(self):
+        self._weights_serial = getattr(self, "_weights_serial", 0) + 1
 
     # -- fused-kernel plumbing -----------------------------------------------------------------
     def is_default_arch(self):

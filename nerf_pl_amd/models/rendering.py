@@ -18,11 +18,14 @@ from .. import draws as D
 from .. import ops
 from .mlp_autograd import _needs_grad, mlp_rays
 
-# test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too: since round 6 its
-# coarse sub-passes run the network's sigma-only body (nerfhip_render_test_fwd), so the launch does exactly the FLOPs of the five
-# launches it replaces (round 5's form evaluated the full coarse network: +21 % coarse FLOPs, and lost to the launches).
-# NERFHIP_FUSE_TEST_TIME=0 keeps the launches (A/B; bit-identical results either way: tests/test_gpu_render_fused.py).
-FUSE_TEST_TIME = os.environ.get("NERFHIP_FUSE_TEST_TIME", "1") == "1"
+# test_time renders (eval.py: coarse pass sigma-only, rendering.py:209-213) through the single-launch kernel too?  Since round 6 its
+# coarse sub-passes run the network's sigma-only body (nerfhip_render_test_fwd): exactly the FLOPs of the five launches, bit-identical
+# results (tests/test_gpu_render_fused.py).  Measured on MI355X, 800 x 800 image in 32768-ray chunks incl. D2H, same box, alternating
+# (profiles/r06_eval_single_launch_ab.txt): 136.9 / 136.9 ms single launch against 135.8 / 135.8 ms for the launches — at 8192
+# workgroups per chunk the launches each fill the chip, while a workgroup of the single launch idles its MFMA pipe during its
+# compositing phases (one workgroup per CU: nothing else to run there) — so the launches stay the default for test_time;
+# NERFHIP_FUSE_TEST_TIME=1 selects the single launch (one graph node per chunk instead of five).
+FUSE_TEST_TIME = os.environ.get("NERFHIP_FUSE_TEST_TIME", "0") == "1"
 
 __all__ = ['render_rays']
 

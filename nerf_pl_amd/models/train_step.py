@@ -55,6 +55,13 @@ def _forward_launches(models, rays, rgbs, S, N, dtype, use_disp, perturb, pertur
     return outs, entries, out3
 
 
+def _tracked(model):
+    """the model's weights are updated by a LIVE optimizer that announces its updates (optim.FlatAdam marks the model with a weak
+    reference to itself); load_state_dict bumps the serial on its own (models/nerf.py)"""
+    ref = getattr(model, "_serial_tracked", None)
+    return ref is not None and ref() is not None
+
+
 class _TrainRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, rays, rgbs, *params):
@@ -79,7 +86,7 @@ class _TrainRender(torch.autograd.Function):
         # (only models whose optimizer ANNOUNCES its updates — FlatAdam bumps `_weights_serial` and marks `_serial_tracked` — can
         # vouch for a pack made before this call; under any other optimizer the serials never move and the images are re-packed)
         fresh = (packed is not None and packed[0] == tuple(id(m) for m in models) and packed[1] == dtype
-                 and all(getattr(m, "_serial_tracked", False) and getattr(m, "_weights_serial", 0) == sr
+                 and all(_tracked(m) and getattr(m, "_weights_serial", 0) == sr
                          and getattr(m, "_packed_serial", None) == sr for m, sr in zip(models, packed[2])))
         packs = [m.train_buffers(dtype, dev) for m in models] if fresh else ops.pack_models_train(models, dtype)
         # d mean((rgb - t)^2) / d rgb = (rgb - t) * (2 / n), the quotient formed in fp32 like nerfhip_mse_psnr's `2.0f / (float)n`

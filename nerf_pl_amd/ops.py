@@ -291,6 +291,9 @@ def composite_train_fine_z(raw, z, rays, noise, noise_std, white_back, target, g
 
 
 _TICKETS = {}
+_CAPTURES = {}
+_EAGER_SLOTS = {}
+_TICKET_WORDS = 1024
 
 
 def _check_draw(op, name, t, numel):
@@ -301,13 +304,27 @@ def _check_draw(op, name, t, numel):
 
 
 def _ticket(device):
-    """one zero-initialised device word per (GPU, stream) for the arrival-ticket kernels (they leave it at zero): launches on one
-    stream are ordered and may share it; two streams (two systems, forked graph branches) must not race on one word"""
-    key = (device.index, torch.cuda.current_stream(device).stream_id)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(4, device=device, dtype=torch.int32)
-    return t
+    """One zero-initialised device word for the arrival-ticket kernels (they leave it at zero).  Eager launches on one stream are
+    ordered and share the word of their (GPU, stream).  A hipGraph is different: it is replayed on whatever stream is current then,
+    so two graphs CAPTURED on one stream may run concurrently — every capture therefore gets a word of its own: a new
+    capture is recognised by the stream's capture status going from "none" to "active" between two calls."""
+    st = torch.cuda.current_stream(device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    rec = _CAPTURES.setdefault((device.index, st.stream_id), [False, 0])
+    if capturing and not rec[0]:
+        rec[1] += 1
+    rec[0] = capturing
+    pool = _TICKETS.get(device.index)
+    if pool is None:
+        if capturing:
+            raise NerfHipError("the ticket words of this GPU must exist before a capture: run the step once eagerly first")
+        pool = _TICKETS[device.index] = torch.zeros(_TICKET_WORDS * 4, device=device, dtype=torch.int32)
+    # slots 0..31: eager use, one per stream in order of first use; 32..: captures, in order (16-byte pitch)
+    if capturing:
+        slot = 32 + rec[1] % (_TICKET_WORDS - 32)
+    else:
+        slot = _EAGER_SLOTS.setdefault((device.index, st.stream_id), len([k for k in _EAGER_SLOTS if k[0] == device.index]) % 32)
+    return pool[4 * slot:4 * slot + 4]
 
 
 @device_guard

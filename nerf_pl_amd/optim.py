@@ -13,6 +13,7 @@ optimizer — and a Lightning checkpoint's `optimizer_states` (train.py `resume_
 state moves between this class and the reference's Adam in both directions.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -29,8 +30,10 @@ class FlatAdam(torch.optim.Optimizer):
         self.flats = []
         for m in self.models:
             self.flats.append(torch.nn.Parameter(self._flatten(m), requires_grad=True))
-            m._serial_tracked = True      # this optimizer announces every update (_bump_serial): weight images packed AHEAD of a
-                                          # step (RayStore.sample(pack_models=...)) may be trusted while the serial stands
+            # this optimizer announces every update (_bump_serial): weight images packed AHEAD of a step
+            # (RayStore.sample(pack_models=...)) may be trusted while the serial stands — and only while THIS optimizer is alive: the
+            # mark is a weak reference, so a model later stepped by another optimizer is not vouched for by a dead FlatAdam
+            m._serial_tracked = weakref.ref(self)
         super().__init__(self.flats, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = self.flats[0].device
         if not self.flats[0].is_cuda:

@@ -14,3 +14,28 @@ def test_layout_maps_are_consistent(tmp_path):
                     os.path.join(ROOT, "tests", "host", "layout_check.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "layout ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_ahead_of_step_weight_images_are_trusted_only_under_a_live_announcing_optimizer():
+    """`_serial_tracked` used to be a flag FlatAdam set and nobody cleared.  It is a weak reference to the optimizer now (a
+    model later stepped by something else is not vouched for by a dead FlatAdam), and load_state_dict — the reference's load_ckpt,
+    utils/__init__.py:55-76 — bumps the weights' serial like an announced update."""
+    import gc
+    import weakref
+
+    from nerf_pl_amd.models import NeRF
+    from nerf_pl_amd.models.train_step import _tracked
+
+    class Opt:                      # stands in for optim.FlatAdam (which needs a GPU): what matters is the weak reference
+        pass
+    m = NeRF()
+    assert not _tracked(m)
+    opt = Opt()
+    m._serial_tracked = weakref.ref(opt)
+    assert _tracked(m)
+    del opt
+    gc.collect()
+    assert not _tracked(m)
+    before = getattr(m, "_weights_serial", 0)
+    m.load_state_dict(NeRF().state_dict())
+    assert m._weights_serial == before + 1
