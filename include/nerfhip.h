@@ -85,10 +85,15 @@ int nerfhip_sample_pdf(const float* bins, int64_t bins_stride, const float* weig
 
 /* Rounding of the pdf normaliser `torch.sum(weights, -1)` (rendering.py:30), on whose last bit the searchsorted indices of
  * rendering.py:42 have knife edges (u == 1.0, cdf ties):
- *   NERFHIP_ROW_TOTAL_EXACT  the correctly rounded fp32 sum (host-independent; what nerfhip_sample_pdf / nerfhip_fine_z use)
+ *   NERFHIP_ROW_TOTAL_EXACT  the correctly rounded fp32 sum (host-independent).  What the plain entry points without a row_total
+ *                            argument — nerfhip_sample_pdf, nerfhip_fine_z — use.
  *   NERFHIP_ROW_TOTAL_ATEN   the fp32 additions in the order of ATen's CPU sum kernel (torch 2.x, every x86 capability:
  *                            8-float vectors, 4 interleaved accumulators, scalar tail) = the reference's own bits on CPU;
- *                            reproduces the (cdf, u) -> inds triples recorded at the reference's call site on every element */
+ *                            reproduces the (cdf, u) -> inds triples recorded at the reference's call site on every element.
+ *                            What the Python operators (nerf_pl_amd.ops: sample_pdf_u, fine_z, render_rays, the fused training
+ *                            step) pass BY DEFAULT through the entry points that take row_total (ops.set_row_total("exact") /
+ *                            NERFHIP_ROW_TOTAL=exact selects the other): over the minted reference training runs the HIP fp32
+ *                            path then follows the reference's PSNR@step with half the seed-to-seed scatter (oracle and parity). */
 #define NERFHIP_ROW_TOTAL_EXACT 0
 #define NERFHIP_ROW_TOTAL_ATEN 1
 

@@ -1006,11 +1006,14 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 // the others (profiles/r04_dw_probe_bf16_table_plan.txt) and the launch SLOWER: 473-480 us against 455-458 us in the same call —
 // with the linear model the first-layer and dir-layer workgroups finish ~15 % early, and the bandwidth they release goes to the
 // 256 x 256 and skip-layer workgroups that end the launch, whose partial slabs then do not all land in the same microseconds.
+// Round 6: with the 2 x 4 wave split, the dot2 bias sums and the register-major epilogue an iteration's fixed part shrank; the sweep of
+// profiles/r06_dw_plan_cost_ab.txt (one box, three alternating rounds) has 150 + 45 / KiB at 449-452 us in the step against 466-469 us for
+// round 4's 300 + 35 / KiB, 100 + 50 the same, 50 + 55 and 0 + 60 (bytes-proportional) slower again.
 #ifndef NERFHIP_DW_COST_A
-#define NERFHIP_DW_COST_A 300
+#define NERFHIP_DW_COST_A 150
 #endif
 #ifndef NERFHIP_DW_COST_B
-#define NERFHIP_DW_COST_B 35
+#define NERFHIP_DW_COST_B 45
 #endif
 #ifndef NERFHIP_DW_FOLD_SIGMA
 #define NERFHIP_DW_FOLD_SIGMA 1      // the final layer's workgroups also form the sigma head's gradient (same X: h8 read once)

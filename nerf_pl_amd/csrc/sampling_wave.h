@@ -30,7 +30,8 @@ __device__ __forceinline__ int upper_bound(P a, int n, float v) {
 // ---- shared per-wave inverse-CDF machinery ---------------------------------------------------
 // Row total of the pdf normaliser (rendering.py:30, `torch.sum(weights, -1, keepdim=True)` on fp32), two selectable roundings:
 //   ROW_TOTAL_EXACT  the fp64 sum of the fp32 terms rounded once — the correctly rounded total (exact here: the terms span < 29
-//                    binades), independent of any host; the default
+//                    binades), independent of any host; the default ARGUMENT of the wave helpers below and what the C entry points
+//                    without a row_total parameter use (the Python operators pass ROW_TOTAL_ATEN by default: ops.set_row_total)
 //   ROW_TOTAL_ATEN   the value ATen's CPU kernel returns, bit for bit: its fp32 additions in its own order (SumKernel.cpp
 //                    cascade_sum -> vectorized_inner_sum -> row_sum: 8-float vectors — on every x86 capability of torch 2.x,
 //                    AVX-512 builds included — four interleaved vector accumulators ("ILP") with a 16-step cascade, the

@@ -37,25 +37,29 @@ def test_benchmark_step_is_one_round_of_the_256_cus(lib):
         assert [k for j, k in enumerate(kb) if j % 12 not in (8, 10)] == [unit * k for j, k in enumerate(STAGE_KIB * 2) if j % 12 not in (8, 10)]
 
 
-ITER_COST = {10: 72, 18: 95, 20: 94, 26: 113, 32: 158, 34: 170, 36: 181}   # 10 ns ticks per ring iteration by stage KiB (tools/dw_probe.py, round 4)
+def iter_cost(kib):
+    """Round 6 cost model of one ring iteration of the bf16 kernel, in ns: 150 + 45 per KiB of its stage (csrc/mlp_bwd.hip
+    NERFHIP_DW_COST_A/B; sweep in profiles/r06_dw_plan_cost_ab.txt).  Round 4's kernel measured 0.7-1.8 us per iteration
+    (tools/dw_probe.py) and planned with 300 + 35 per KiB; the 2 x 4 wave split, dot2 bias sums and register-major epilogue of
+    round 6 shrank the fixed part, and the sweep then preferred a plan nearer to bytes-proportional."""
+    return 150 + 45 * kib
 
 
 def test_bf16_plan_equalises_time_not_iterations(lib):
-    """Round 4 (tools/dw_probe.py): an iteration of the bf16 kernel costs 0.7-1.8 us depending on its stage's bytes, so equal
-    iteration counts left the skip-layer workgroups 17 % behind the 256 x 256 layers and the small heads idle for a third of the
-    launch.  The plan balances iterations x (0.3 us + 35 ns per KiB) — deliberately not the measured table, which finishes every
-    workgroup within 3 % of the others and runs the launch 4 % slower (csrc/mlp_bwd.hip): the slowest workgroup within 12 % of the mean."""
+    """An iteration of the bf16 kernel costs more the more bytes its stage holds, so equal iteration counts leave the skip-layer
+    workgroups behind the 256 x 256 layers and the small heads idle for part of the launch.  The plan balances
+    iterations x iter_cost(stage KiB): the slowest workgroup within 8 % of the mean under that model."""
     pts = [1024 * 192, 1024 * 64]
     total, sp, kb = _plan(lib, pts, BF16)
     t = []
     for j, (s, k) in enumerate(zip(sp, kb)):
         tiles = pts[j // 12] // 32
-        t.append(-(-tiles // s) * ITER_COST[k] if s else 0)
+        t.append(-(-tiles // s) * iter_cost(k) if s else 0)
     mean = sum(ti * s for ti, s in zip(t, sp)) / total
-    assert max(t) <= 1.12 * mean, (max(t), mean, sp)
+    assert max(t) <= 1.08 * mean, (max(t), mean, sp)
     assert sp[4] > sp[1] > sp[0] > sp[11]            # skip layer (36 KiB) > 256 x 256 (32) > first (20) > rgb head (10)
     # equal iteration counts would be 18 % off
-    eq = [384 * ITER_COST[k] for k in kb[:12] if k] + [-(-2048 // s) * ITER_COST[k] for s, k in zip([5, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5], kb[12:]) if k]
+    eq = [384 * iter_cost(k) for k in kb[:12] if k] + [-(-2048 // s) * iter_cost(k) for s, k in zip([5, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5], kb[12:]) if k]
     assert max(eq) > 1.15 * mean
     # the e4m3 kernel keeps equal iteration counts (measured: 254 us against 336 us with a byte-weighted plan)
     total, sp8, _ = _plan(lib, pts, BF16_F8)
