@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from bench_inputs import (DTYPE_LABEL, FLOP_PER_POINT_DW, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, FLOP_PER_RAY_EVAL,  # noqa: E402
+from bench_inputs import (DTYPE_LABEL, PARITY, FLOP_PER_POINT_DW, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, FLOP_PER_RAY_EVAL,  # noqa: E402
                           PEAK_HBM_GBS, PEAK_TFLOPS, cpu_baseline, synth_params, synth_rays, synth_store, synth_store_ndc)
 
 PROTOCOL_VERSION = 3      # 1: rounds 1-3 (build calls counted as warm-up); 2: rounds 4-5 (build + settle replays outside W + K, value = sustained,
@@ -506,6 +506,7 @@ def main():
                                    "value (W + K).  Rounds 4-5 (protocol 2) printed the same sustained `value` and the first K replays without "
                                    "warm-up as cold_start_ms_per_step; rounds 1-3 (protocol 1) counted the build calls as warm-up steps"}
         out.update(extra)
+        out["parity"] = PARITY
         if not a.no_cpu_baseline and world == 1:                # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(B, S, N, a.cpu_seconds, a.mode == "train")
         real_stdout.write(json.dumps(out) + "\n")

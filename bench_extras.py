@@ -190,7 +190,7 @@ def event_time(fn, reps, warm=3, graph=False):
 def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
     """Per-kernel roofline entries for the MLP kernels of the TIMED training step (fine pass B x (S+N) points and coarse
     pass B x S points): HIP-event time of each kernel on resident buffers, algorithmic FLOPs and HBM bytes
-    (DESIGN.md §6), fractions of the dense MFMA peak of the kernel's arithmetic and of the 8 TB/s HBM peak.
+    (DESIGN.md §7), fractions of the dense MFMA peak of the kernel's arithmetic and of the 8 TB/s HBM peak.
     merged: the step runs ONE weight-gradient launch and ONE reduce launch for both models (the fused step at N = 1)."""
     from nerf_pl_amd import _lib, ops
     lib = _lib.load()
