@@ -83,6 +83,9 @@ __device__ __forceinline__ void glds16b_s(const void* sbase, unsigned voff, unsi
 // 226.9 -> 217.5 us with depth 2 (depth 1: 216-218, depth 3: 219); the e5m2-storing variant sits at its 256-register budget,
 // where the ring costs 16-48 spilled registers: 209.3 (none) / 212 (1) / 212 (2) / 222 us (3) — the two waves of a SIMD already
 // cover each other's LDS round trips there.
+#ifndef NERFHIP_CHAIN_BURST
+#define NERFHIP_CHAIN_BURST 2
+#endif
 #ifndef NERFHIP_CHAIN_DEPTH
 #define NERFHIP_CHAIN_DEPTH 2
 #endif
@@ -350,8 +353,14 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
             // per-tile offsets are immediates (soffset stays 0: gfx950 store-data hazard, see store_slab)
             __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab) * act_il(PREC), 0,
                                                                               (int)(2 * NT * 64 * sizeof(Slab) * act_il(PREC)), 0x00020000);
+            // NERFHIP_CHAIN_BURST slabs per run of back-to-back stores (2 = each tile's pair as soon as it is gated; the slabs of a
+            // layer stay in registers as the next layer's operands anyway, so holding a run back costs no register)
+            constexpr int TB = NERFHIP_CHAIN_BURST / 2 > 0 ? NERFHIP_CHAIN_BURST / 2 : 1;
+            if constexpr ((t + 1) % TB == 0 || t == NT - 1) {
+                constexpr int t0 = (t / TB) * TB;
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) store_slab(st, dys_l, 2 * t + sl, out[2 * t + sl], lane);
+                for (int sl = 2 * t0; sl < 2 * t + 2; ++sl) store_slab(st, dys_l, sl, out[sl], lane);
+            }
         }
     });
     if constexpr (F8 && PREC == NERFHIP_BF16) {

@@ -284,6 +284,9 @@ NH_HD constexpr int layer_in_sec(int L) {
 #ifndef NERFHIP_EXP_SMALL
 #define NERFHIP_EXP_SMALL 0     // code-size experiment only (results invalid): no gate words, no running maximum
 #endif
+#ifndef NERFHIP_SAVE_BURST
+#define NERFHIP_SAVE_BURST 1      // 1, 2, 4, 8: divides the 8 / 16 output slabs of every saved layer
+#endif
 #ifndef NERFHIP_PF_SAVE
 #define NERFHIP_PF_SAVE 2
 #endif
@@ -359,7 +362,13 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
     }
     if constexpr (SAVE) {
         const int lane = fresh_lane();
-        if (!F8 && (p & 3) == 3) save_slabs(st, cx.tile, layer_out_sec(PL) + 2 * pt + (p >> 2), &o, 1, lane);
+        // NERFHIP_SAVE_BURST slabs per run of back-to-back stores (1 = each slab as soon as it is packed; a layer's slabs stay in
+        // registers as the next layer's operands, so holding a run back costs no register)
+        if (!F8 && (p & 3) == 3) {
+            const int si = 2 * pt + (p >> 2);
+            if ((si + 1) % NERFHIP_SAVE_BURST == 0)
+                save_slabs(st, cx.tile, layer_out_sec(PL) + si + 1 - NERFHIP_SAVE_BURST, &po[si + 1 - NERFHIP_SAVE_BURST], NERFHIP_SAVE_BURST, lane);
+        }
         if (RELU && p == 7 && (pt & 1)) {
             __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(cx.gate_base + layer_gate_piece(PL) * kPieceBytes * act_il(PREC, F8), 0,
                                                                            kPieceBytes, 0x00020000);
