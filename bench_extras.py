@@ -13,7 +13,7 @@ import sys
 
 import torch
 
-from bench_inputs import (FLOP_PER_POINT_DW, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, PEAK_HBM_GBS, PEAK_TFLOPS, PEAK_TFLOPS_FP8, ROOT,
+from bench_inputs import (FLOP_PER_POINT_DW, FLOP_PER_POINT_DW_EXECUTED, UNSAVED_SLABS_PER_TILE, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, PEAK_HBM_GBS, PEAK_TFLOPS, PEAK_TFLOPS_FP8, ROOT,
                           TRAFFIC_JSON, synth_params, synth_rays)
 
 BENCH_PY = os.path.join(ROOT, "bench.py")
@@ -203,8 +203,19 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
 
     todo = []                          # (name, tag, P, fn, flops, nbytes, what, key): timed together below, in the step's order
 
-    def entry(name, tag, P, fn, flops, nbytes, what, key_name=None):
+    executed = {}                      # key -> FLOPs the launch executes, where that is less than the algorithmic figure
+
+    def entry(name, tag, P, fn, flops, nbytes, what, key_name=None, flops_executed=None):
         todo.append((name, tag, P, fn, flops, nbytes, what, key_name or name))
+        if flops_executed is not None:
+            executed[(key_name or name, P)] = flops_executed
+
+    # bytes of a buffer's 16 never-touched slab slots per 32-point tile (the buffers keep the slots: csrc/mlp_layout.h kActFeat / kDyFeat)
+    slab_b = {"fp32": 2048, "bf16": 1024, "bf16_f8": 512}[dtype]
+
+    def unsaved(P):
+        ppw = 128 if dtype == "fp32" else 256
+        return (P + ppw - 1) // ppw * (ppw // 32) * UNSAVED_SLABS_PER_TILE * slab_b
 
     keep, entries, dw_b, P_all, chain_b = [], [], 0, 0, 0
     one_fwd = merged and ops.render_supported(B, S, N, dtype)       # the step's forward is ONE launch (nerfhip_render_train_fwd)
@@ -218,10 +229,10 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         g_out = torch.randn_like(raw)
         ws = {}
         ops.mlp_bwd(g_out, raw, pb, acts, dtype, workspace=ws)
-        act_b, dy_b = acts.numel(), ws["dys"].numel()
+        act_b, dy_b = acts.numel() - unsaved(P), ws["dys"].numel() - unsaved(P)        # bytes written / read, not allocated
         gate_b = (P + 31) // 32 * 9 * 1024
-        # split-K partials the reduce kernel reads: per split 592 used (out-tile, x-tile) blocks of 4 KiB over the 12 jobs
-        ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 12 * 592 * 4096
+        # split-K partials the reduce kernel reads: per split 528 used (out-tile, x-tile) blocks of 4 KiB over the 10 jobs with workgroups
+        ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 10 * 528 * 4096
         if not one_fwd:
             entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
                   FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
@@ -234,7 +245,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         if not merged:
             entry("mlp_bwd_dw_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=2, workspace=ws),
-                  FLOP_PER_POINT_DW * P, (act_b - gate_b) + dy_b, "every saved activation and dY slab read once")
+                  FLOP_PER_POINT_DW * P, (act_b - gate_b) + dy_b, "every saved activation and dY slab read once",
+                  flops_executed=FLOP_PER_POINT_DW_EXECUTED * P)
             entry("mlp_bwd_reduce_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=4, workspace=ws),
                   0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written")
@@ -258,13 +270,14 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         ops.mlp_bwd_multi(entries, dtype, workspace=wsm)            # (chains included: fills the dY slabs the dW launch reads)
         n_arr = (__import__("ctypes").c_int64 * 2)(*[e[1].numel() // 4 for e in entries])
         n_slabs = int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, 2, code)) // (4 * (8 * 10 * 64 * 16 + 8 * 64))
-        ws_b = n_slabs * 592 * 4096 // 12        # average used blocks per partial slab (592 of a model's 12 jobs together)
+        ws_b = n_slabs * 528 * 4096 // 10        # average used blocks per partial slab (528 of a model's 10 jobs with workgroups together)
         entry("mlp_bwd_chain_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=1, workspace=wsm),
               FLOP_PER_POINT_DX * P_all, chain_b, "dY of both models written once, ReLU gate words + g_out/out read", key_name="mlp_bwd_chain_kernel<merged>")
         entry("mlp_bwd_dw_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=2, workspace=wsm),
-              FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>")
-        entry("mlp_bwd_reduce_kernel", "both models in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=4, workspace=wsm),
-              0, ws_b + 4 * 595844 * 4, "split-K partial slabs read, 48 gradient tensors written", key_name="mlp_bwd_reduce_kernel<merged>")
+              FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>",
+              flops_executed=FLOP_PER_POINT_DW_EXECUTED * P_all)
+        entry("mlp_bwd_reduce_kernel", "both models in ONE launch, + mlp_bwd_fold_kernel behind it", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=4, workspace=wsm),
+              0, ws_b + 4 * 595844 * 4, "split-K partial slabs read, 48 gradient tensors written (6 of them by the fold launch)", key_name="mlp_bwd_reduce_kernel<merged>")
     # Timing: each kernel replayed alone (12 launches captured in a hipGraph: no host gaps).  One kernel repeated back to back
     # settles at its own shader clock, which on some boxes is LOWER than inside the step's mix of MFMA-bound and HBM-bound kernels
     # (HIP events between the nodes of one graph do not time on this stack: hipErrorInvalidHandle); the six kernels are therefore
@@ -312,6 +325,11 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
                     "frac_mfma_in_step": round(flops / max(in_mix[k], 1e-3) / 1e6 / peak, 4),
                     "frac_hbm_in_step": round(nbytes / max(in_mix[k], 1e-3) / 1e3 / PEAK_HBM_GBS, 4),
                     "traffic": traffic_db.get(key, {}).get("hbm_bytes_per_launch")})
+        if (key_name, P) in executed:
+            fe = executed[(key_name, P)]
+            out[-1].update({"flops_executed": fe, "frac_mfma_executed_in_step": round(fe / max(in_mix[k], 1e-3) / 1e6 / peak, 4),
+                            "flops_note": "`flops` = the reference's weight-gradient GEMMs (SURVEY 8d); the launch executes `flops_executed`: "
+                                          "the final layer's gradients come from the dir job's G by two small fp32 products"})
     out.sort(key=lambda r: -r["avg_launch_us"])
     del keep, entries, todo
     return out, round(mix_us, 1)

@@ -13,7 +13,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 FLOP_PER_POINT_FULL = 1186816      # 593,408 MAC, GEMMs only, no padding counted
 FLOP_PER_POINT_DX = 1115392        # backward chain: 557,696 MAC (no dX into the encodings)
-FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC
+FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC (the reference's autograd: what `frac` prices)
+# ... of which the dW launch EXECUTES 527,872 MAC since round 6: xyz_encoding_final has no activation, so its two gradients follow
+# from G = dY_dir^T h8 (the dir job, same size as before) by two small fp32 products per step instead of a 256 x 256 x P GEMM
+# (csrc/mlp_layout.h kDwJobs).  Reported beside the algorithmic figure as `flops_executed` / `frac_mfma_executed_in_step`.
+FLOP_PER_POINT_DW_EXECUTED = FLOP_PER_POINT_DW - 2 * 256 * 256
+UNSAVED_SLABS_PER_TILE = 16        # slab slots of a 32-point tile block that nobody writes or reads: f in X, dL/df in dY (same source)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks of the forward / dX chain
 PEAK_TFLOPS_FP8 = 5000.0           # ... and of the MX-scaled fp8 MFMA the dW GEMM of bf16_f8 runs on

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERFHIP_ABI_VERSION 1
+#define NERFHIP_ABI_VERSION 2     /* 2: nerfhip_mlp_pack_weights_bwd takes the biases (fold block of the W^T image) */
 
 #define NERFHIP_E_BADARG (-1)  /* null pointer / non-positive size / unsupported shape */
 #define NERFHIP_E_UNSUPPORTED (-2)
@@ -195,14 +195,19 @@ int nerfhip_mlp_fwd_rays_coarse(const float* rays, const float* perturb_rand, fl
  * (writes dL/d(pre-activation) slabs into `dys`), then dW = dY^T X with points as the MFMA K
  * dimension (split-K partial slabs in `dw_workspace`, reduced and un-permuted into the gradients).
  *   g_out (n,4)  dL/d[rgb sigma];  out (n,4) the forward's output (for sigmoid');
- *   packed_bwd   nerfhip_mlp_pack_weights_bwd() image of the CURRENT weights;
+ *   packed_bwd   nerfhip_mlp_pack_weights_bwd() image of the CURRENT parameters: the W^T fragment stream of the chain, then an fp32
+ *                snapshot of xyz_encoding_final's weight + bias and of dir_encoding's first 256 weight columns.  xyz_encoding_final
+ *                has no activation (nerf.py:70,116): the forward does not save its output, the chain does not store its output
+ *                gradient, the dW launch forms G = dY_dir^T h8 and a small fp32 launch (mlp_bwd_fold_kernel) finishes
+ *                dW_dir[:, :256] = G W_f^T + db_dir b_f^T, dW_final = W_dir[:, :256]^T G, db_final = W_dir[:, :256]^T db_dir —
+ *                the same sums, re-associated (csrc/mlp_layout.h kDwJobs);
  *   acts         buffer the forward filled (save_acts);  dys  nerfhip_mlp_dy_bytes() scratch;
  *   dw_workspace nerfhip_mlp_dw_workspace_bytes() scratch;
  *   grad_w_host / grad_b_host: HOST arrays of 12 DEVICE pointers (state_dict order, (out,in) fp32);
  *   accumulate != 0 adds into them, else overwrites.  No gradient flows to rays / z / x
  *   (the reference's sampled depths are detached, rendering.py:226; rays carry no grad).            */
 size_t nerfhip_mlp_packed_bwd_bytes(int dtype);
-int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
+int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, const float* const* biases_host, void* packed_bwd, int dtype,
                                  nerfhip_stream_t stream);
 /* both images (nerfhip_mlp_pack_weights + nerfhip_mlp_pack_weights_bwd) in ONE launch: what a training step needs
  * of a model whose weights do not change between its forward and its backward                                   */

@@ -48,7 +48,7 @@ SIGNATURES = {
     "nerfhip_mlp_fwd_embedded": [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _int, _int, _c_void_p, _c_void_p],
     "nerfhip_mlp_fwd_rays": [_c_void_p, _c_void_p, _i64, _int, _c_void_p, _c_void_p, _int, _int, _c_void_p, _c_void_p],
     "nerfhip_mlp_packed_bwd_bytes": [_int],
-    "nerfhip_mlp_pack_weights_bwd": [ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
+    "nerfhip_mlp_pack_weights_bwd": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p, _int, _c_void_p],
     "nerfhip_mlp_pack_weights_train": [ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p, _int, _c_void_p],
     "nerfhip_mlp_dy_bytes": [_i64, _int],
     "nerfhip_mlp_dw_splits": [_i64, _int],
@@ -160,7 +160,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
-    if lib.nerfhip_abi_version() != 1:
+    if lib.nerfhip_abi_version() != 2:
         raise NerfHipError("libnerfhip ABI version mismatch")
     _lib = lib
     return lib

@@ -12,6 +12,10 @@
 //     accumulators in registers for the whole range, one partial slab per workgroup; mlp_bwd_reduce sums
 //     the slabs, un-permutes features and writes the (out,in) gradient tensors + biases.
 //     HBM-bound by construction: 2*256*256 FLOP per 2*256*2 B = 128 FLOP/B.
+//  C  mlp_bwd_fold   — xyz_encoding_final is a linear layer without activation: its saved input / output gradient are not needed
+//     (mlp_layout.h kDwJobs).  The dir job forms G = dY_dir^T h8 instead of dY_dir^T f; this small fp32 kernel finishes
+//     dW_dir[:, :256] = G W_f^T + s b_f^T,  dW_final = W_dx^T G,  db_final = W_dx^T s  from G, s = db_dir and the fp32 fold block
+//     of the packed W^T image.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -110,18 +114,22 @@ struct DwJobTable {
     const uint8_t* dys[kDwMaxJobs];    // dY slabs of the job's model
     int64_t ntiles[kDwMaxJobs];        // 32-point wave tiles of the job's model
     int njobs;
-    // (bf16: round 4; e4m3 and fp32: round 5)  The sigma head's job has no workgroups of its own — its X is the final layer's X (h8: 16 slabs per tile that the
-    // launch used to read twice, 134 MB of its 2.87 GB) — so the FINAL layer's workgroups also form dW_sigma: fold_of[sigma job] = the
-    // final job's index (its partial slabs hold the sigma partials in the tile column it does not use), -1 everywhere else.
+    // The sigma head's job has no workgroups of its own — its X (h8: 16 slabs per tile) is also the second X section of the DIR job
+    // since round 6 (mlp_layout.h kDwJobs; rounds 4-5: of the final layer's job) — so the dir job's workgroups also form dW_sigma:
+    // their waves 4..7, idle otherwise (the job has 4 dY tiles), each multiply dY_sigma by two of the eight h8 tiles.
+    // fold_of[sigma job] = the dir job's index (its partial slabs hold the sigma partials in rows 4..7, which it does not use),
+    // -1 everywhere else.
     int fold_of[kDwMaxJobs];
 };
-constexpr int kDwJobFinal = 8, kDwJobSigma = 10;       // indices in mlp_layout.h kDwJobs
-static_assert(kDwJobs[kDwJobFinal].x1_off == kDwJobs[kDwJobSigma].x1_off && kDwJobs[kDwJobFinal].x1_slabs == 16 &&
-              kDwJobs[kDwJobSigma].x1_slabs == 16 && kDwJobs[kDwJobSigma].dy_slabs == 2 && kDwJobs[kDwJobFinal].x2_slabs == 0 &&
-              kDwJobs[kDwJobSigma].x2_slabs == 0, "the sigma head and the final layer read the same X section");
-constexpr int kDwFoldCol = 8;          // tile column of the final job's partial slab that holds the sigma partials (it uses columns 0..7)
-constexpr int kDwFoldBiasCol = 9;      // ... and the first 64 floats of (row 0, this column) its bias partial
-static_assert(kDwFoldBiasCol < kDwMaxXTiles, "fold columns inside the slab");
+static_assert(kDwJobs[kDwJobDir].x2_off == kDwJobs[kDwJobSigma].x1_off && kDwJobs[kDwJobDir].x2_slabs == 16 && kDwJobs[kDwJobDir].x1_slabs == 2 &&
+              kDwJobs[kDwJobSigma].x1_slabs == 16 && kDwJobs[kDwJobSigma].dy_slabs == 2 && kDwJobs[kDwJobDir].dy_slabs == 8 &&
+              kDwJobs[kDwJobSigma].x2_slabs == 0, "the sigma head and the dir layer read the same h8 section");
+// the folded sigma head in a dir-job partial slab: wave w = 4..7 holds (dY_sigma tile 0) x (h8 tiles 2 (w - 4), 2 (w - 4) + 1) in
+// blocks (row w, columns 0, 1); its bias partial is bias row kDwFoldRow0 (written by wave 4)
+constexpr int kDwFoldRow0 = 4;
+NH_HD constexpr int dw_fold_block(int xt) { return (kDwFoldRow0 + xt / 2) * kDwMaxXTiles + (xt & 1); }     // block index of h8 tile xt
+constexpr int kDwFoldStageSlabs = 28;  // [dY_dir 8][enc_dir 2][h8 16][dY_sigma 2]
+constexpr int kDwFoldSigmaSlab = 26;   // first dY_sigma slab of that stage
 #ifndef NERFHIP_DW_RING_KB
 #define NERFHIP_DW_RING_KB 160   // bf16 dW ring: the whole LDS of a CU, cut into as many stages as the JOB's stage size allows (round 4; the
                                  // depth itself measured neutral — 4 stages of 36 KiB run the same 480 us — the waves never wait for data)
@@ -260,11 +268,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
     float dbacc = 0.0f;
     [[maybe_unused]] float dbacc2 = 0.0f;             // (second chain of the dot2 bias sums)
-    [[maybe_unused]] f32x16 acc_sig;                  // (folded sigma head, class (8, 34) only)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_sig[r] = 0.0f;
-    [[maybe_unused]] float dbacc_sig = 0.0f;
-    [[maybe_unused]] float dbacc_sig2 = 0.0f;
 
     // per-lane transposing-read geometry (bf16): 16-lane group g reads a [4 points][16 features] tile whose
     // 8-byte chunks are (point row = c>>2, feature block = c&3) of lane c; feature block b lives in half
@@ -288,10 +291,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // vmcnt serves all), D ring stages.
     auto run = [&](auto nxt_c, auto nsl_c) {
         constexpr int NXT = decltype(nxt_c)::value, NSL = decltype(nsl_c)::value;
-        // class (8, 34) = the final layer with the sigma head folded in: stage = [dY_feat 16][h8 16][dY_sigma 2] slabs; every wave
-        // adds ONE MFMA per k-step, dY_sigma x (X tile `wave`), into an accumulator of its own
-        constexpr bool FOLD = NXT == 8 && NSL == 34;               // (bf16 since round 4, fp32 since round 5)
-        // round 6, bf16: the three classes with 8 dY tiles and 8 | 10 X tiles — (8, 32), (8, 34), (10, 36): 85 % of the launch's
+        // class (9, 28) = the dir layer with the sigma head folded in: stage = [dY_dir 8][enc_dir 2][h8 16][dY_sigma 2] slabs; the
+        // waves 4..7 (no dY tile of the dir layer is theirs) multiply dY_sigma by the h8 tiles 2 (w - 4), 2 (w - 4) + 1
+        constexpr bool FOLD = NXT == 9 && NSL == kDwFoldStageSlabs;
+        // round 6, bf16: the classes with 8 dY tiles and 8 | 10 X tiles — (8, 32), (10, 36): 85 % of the launch's
         // workgroups — give wave (wi = wave >> 1, wj = wave & 1) the dY tiles 2 wi, 2 wi + 1 against the X tiles XW wj .. XW wj + XW - 1
         constexpr bool SPLIT2D = (PREC == NERFHIP_BF16) && NERFHIP_DW_SPLIT2D && (NXT == 8 || NXT == 10) && (NSL - 2 * NXT >= 16);
         constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
@@ -331,7 +334,7 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             if (pi >= NP) pi = NP - 1;                                          // (classes without sharing) duplicate DMA of the last piece
             const int sl = pi / SPP, sub = pi % SPP;
             const uint8_t* src;
-            if (FOLD && sl >= 32) src = dbase + (size_t)(kDySigma + sl - 32) * 64 * (16 * SPP) * IL;
+            if (FOLD && sl >= kDwFoldSigmaSlab) src = dbase + (size_t)(kDySigma + sl - kDwFoldSigmaSlab) * 64 * (16 * SPP) * IL;
             else if (sl < jb.dy_slabs) src = dbase + (size_t)(jb.dy_off + sl) * 64 * (16 * SPP) * IL;
             else if (sl < jb.dy_slabs + jb.x1_slabs) src = abase + (size_t)(jb.x1_off + sl - jb.dy_slabs) * 64 * (16 * SPP) * IL;
             else src = abase + (size_t)(jb.x2_off + sl - jb.dy_slabs - jb.x1_slabs) * 64 * (16 * SPP) * IL;
@@ -390,14 +393,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                 };
                 // piece k of the next stage is issued behind B step dma_after(k): the LPW DMAs spread evenly over the NF steps
                 auto dma_after = [](int k) constexpr { return ((k + 1) * NF) / LPW - 1; };
-                [[maybe_unused]] bf16x8 as0, as1, bs0, bs1;
-                if constexpr (FOLD) {                 // dY_sigma (slabs 32, 33 of the stage) against X tile 4 wj + wi: the 8 waves cover tiles 0..7
-                    const char* xs = x_all + 2 * (4 * wj + wi) * SLAB_BYTES;
-                    as0 = load_frag(st_base + 32 * SLAB_BYTES, 0);
-                    bs0 = load_frag(xs, 0);
-                    as1 = load_frag(st_base + 32 * SLAB_BYTES, 1);
-                    bs1 = load_frag(xs, 1);
-                }
                 bf16x8 a[2][2], b[RD];
                 a[0][0] = load_frag(dyb, 0);
                 a[0][1] = load_frag(dyb + 2 * SLAB_BYTES, 0);
@@ -416,18 +411,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     if (f == 0 || f == XW) {          // bias partial of dY tile 2 wi + wj (its two waves share the pair's two tiles)
                         const bf16x8 ab = wj ? a[f / XW][1] : a[f / XW][0];
                         dw_bias_sum(ab, dbacc, dbacc2);
-                    }
-                    if constexpr (FOLD) {
-                        if (f == 1) {
-                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as0, bs0, acc_sig, 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            dw_bias_sum(as0, dbacc_sig, dbacc_sig2);
-                        }
-                        if (f == XW + 1) {
-                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as1, bs1, acc_sig, 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            dw_bias_sum(as1, dbacc_sig, dbacc_sig2);
-                        }
                     }
                     if constexpr (SPREAD) {
 #pragma unroll
@@ -454,13 +437,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     // round trips per ring stage with both waves of a SIMD in lock-step), and the bias sums (16 VALU per k-step)
                     // sit behind the first MFMAs instead of in front of them.
                     constexpr int RD = NERFHIP_DW_RD, NM = 2 * NXT;
-                    [[maybe_unused]] bf16x8 as0, as1, bs0, bs1;
-                    if constexpr (FOLD) {                                 // dY_sigma (slabs 32, 33 of the stage) and X tile `wave`
-                        as0 = load_frag(st_base + 32 * SLAB_BYTES, 0);
-                        bs0 = load_frag(x_base + 2 * wave * SLAB_BYTES, 0);
-                        as1 = load_frag(st_base + 32 * SLAB_BYTES, 1);
-                        bs1 = load_frag(x_base + 2 * wave * SLAB_BYTES, 1);
-                    }
                     const bf16x8 a0 = load_frag(dy_base, 0);
                     bf16x8 b[RD];
 #pragma unroll
@@ -476,18 +452,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                         acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m < NXT ? a0 : a1, b[m % RD], acc[x], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         if (m == 1) dw_bias_sum(a0, dbacc, dbacc2);
-                        if constexpr (FOLD) {
-                            if (m == 3) {
-                                acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as0, bs0, acc_sig, 0, 0, 0);
-                                __builtin_amdgcn_sched_barrier(0);
-                                dw_bias_sum(as0, dbacc_sig, dbacc_sig2);
-                            }
-                            if (m == NXT + 3) {
-                                acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as1, bs1, acc_sig, 0, 0, 0);
-                                __builtin_amdgcn_sched_barrier(0);
-                                dw_bias_sum(as1, dbacc_sig, dbacc_sig2);
-                            }
-                        }
                         if (m == NXT + 1 || (NXT == 1 && m == 1)) dw_bias_sum(a1, dbacc, dbacc2);
                         if constexpr (SPREAD) {
                             if (m % DMA_STEP == DMA_STEP - 1 && m / DMA_STEP < LPW) {
@@ -511,12 +475,40 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                             const float b = *reinterpret_cast<const float*>(x_base + 2 * x * SLAB_BYTES + f32_off + pt * 32);
                             acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x], 0, 0, 0);
                         }
-                        if constexpr (FOLD) {                          // dY_sigma (slabs 32, 33 of the stage) x X tile `wave`
-                            const float as = *reinterpret_cast<const float*>(st_base + 32 * SLAB_BYTES + f32_off + pt * 32);
-                            const float bs = *reinterpret_cast<const float*>(x_base + 2 * wave * SLAB_BYTES + f32_off + pt * 32);
-                            dbacc_sig += as;
-                            acc_sig = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc_sig, 0, 0, 0);
-                        }
+                    }
+                }
+            } else if constexpr (FOLD) {
+                // the folded sigma head: wave w = 4..7, dY_sigma (one tile) x the h8 tiles 2 (w - 4), 2 (w - 4) + 1 = X tiles 1 + .. of
+                // the stage (tile 0 is enc_dir) into acc[0], acc[1]; wave 4 also sums dY_sigma for the bias
+                const char* sg = st_base + kDwFoldSigmaSlab * SLAB_BYTES;
+                const char* xs = st_base + (jb.dy_slabs + 2 * (1 + 2 * (wave - kDwFoldRow0))) * SLAB_BYTES;
+                if constexpr (PREC == NERFHIP_BF16) {
+                    auto load_frag = [&](const char* pb, int q) {
+                        union { s16x4 h2[2]; bf16x8 v; } f;
+                        f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s0));
+                        f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + tr_off + q * 512 + tr_s1));
+                        return f.v;
+                    };
+                    const bf16x8 a0 = load_frag(sg, 0), b00 = load_frag(xs, 0), b10 = load_frag(xs + 2 * SLAB_BYTES, 0);
+                    const bf16x8 a1 = load_frag(sg, 1), b01 = load_frag(xs, 1), b11 = load_frag(xs + 2 * SLAB_BYTES, 1);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b00, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b10, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b01, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b11, acc[1], 0, 0, 0);
+                    if (wave == kDwFoldRow0) {
+                        dw_bias_sum(a0, dbacc, dbacc2);
+                        dw_bias_sum(a1, dbacc, dbacc2);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const int pt = 2 * ks + kk;
+                        const float a = *reinterpret_cast<const float*>(sg + f32_off + pt * 32);
+                        dbacc += a;
+                        const float b0 = *reinterpret_cast<const float*>(xs + f32_off + pt * 32);
+                        const float b1 = *reinterpret_cast<const float*>(xs + 2 * SLAB_BYTES + f32_off + pt * 32);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
                     }
                 }
             }
@@ -528,7 +520,6 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         // this workgroup's partial sums: [dY tile][X tile] blocks of 1024 floats (dw_store_block) + one bias row per dY tile
         float* sl = slabs + (size_t)blockIdx.x * kDwSlabFloats;
         dbacc += dbacc2;
-        dbacc_sig += dbacc_sig2;
         if constexpr (SPLIT2D) {
             constexpr int XW = NXT / 2;
             const int wi = wave >> 1, wj = wave & 1;
@@ -538,18 +529,14 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                 for (int d = 0; d < 2; ++d)
                     dw_store_block(sl + (size_t)((2 * wi + d) * kDwMaxXTiles + XW * wj + xl) * 1024, acc[2 * xl + d], lane);
             sl[8 * kDwMaxXTiles * 64 * 16 + (2 * wi + wj) * 64 + lane] = dbacc;
-            if constexpr (FOLD) {                // the sigma head's (dY tile 0, X tile t = 4 wj + wi) partial: row t, column kDwFoldCol
-                dw_store_block(sl + (size_t)((4 * wj + wi) * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
-                if (wave == 0) sl[((size_t)(0 * kDwMaxXTiles + kDwFoldBiasCol) * 64) * 16 + lane] = dbacc_sig;
-            }
         } else if (wave < n_ot) {
 #pragma unroll
             for (int x = 0; x < NXT; ++x) dw_store_block(sl + (size_t)(wave * kDwMaxXTiles + x) * 1024, acc[x], lane);
             sl[8 * kDwMaxXTiles * 64 * 16 + wave * 64 + lane] = dbacc;
-            if constexpr (FOLD) {                // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
-                dw_store_block(sl + (size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
-                if (wave == 0) sl[((size_t)(0 * kDwMaxXTiles + kDwFoldBiasCol) * 64) * 16 + lane] = dbacc_sig;
-            }
+        } else if constexpr (FOLD) {             // the sigma head's partials: blocks dw_fold_block(2 (w - 4)), (.. + 1); bias row kDwFoldRow0
+            dw_store_block(sl + (size_t)dw_fold_block(2 * (wave - kDwFoldRow0)) * 1024, acc[0], lane);
+            dw_store_block(sl + (size_t)dw_fold_block(2 * (wave - kDwFoldRow0) + 1) * 1024, acc[1], lane);
+            if (wave == kDwFoldRow0) sl[8 * kDwMaxXTiles * 64 * 16 + kDwFoldRow0 * 64 + lane] = dbacc;
         }
     };
     // job classes of mlp_layout.h kDwJobs: (X tiles, dY + X slabs per stage)
@@ -558,12 +545,14 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         case 2: run(integral_constant<int, 2>{}, integral_constant<int, 20>{}); break;                 // first layer: 16 + 4
         case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}); break;                 // rgb head: 2 + 8
         case 8:
-            if (jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
-                run(integral_constant<int, 8>{}, integral_constant<int, 34>{});                        // final layer + folded sigma head: 16 + 16 + 2
-            else if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
-            else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head: 2 + 16
+            if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
+            else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head on its own: 2 + 16
             break;
-        case 9: run(integral_constant<int, 9>{}, integral_constant<int, 26>{}); break;                 // dir layer: 8 + 18
+        case 9:
+            if (jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
+                run(integral_constant<int, 9>{}, integral_constant<int, kDwFoldStageSlabs>{});         // dir layer + folded sigma head: 8 + 18 + 2
+            else run(integral_constant<int, 9>{}, integral_constant<int, 26>{});                       // dir layer: 8 + 18
+            break;
         default: run(integral_constant<int, 10>{}, integral_constant<int, 36>{}); break;               // skip layer: 16 + 20 (kDwMaxXTiles)
     }
 #if NERFHIP_DW_PROBE
@@ -649,8 +638,9 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     const uint8_t* __restrict__ dys_base = jobs.dys[jid];
     const int dyp = jb.dy_slabs / 2, x1p = jb.x1_slabs / 2, x2p = jb.x2_slabs / 2;
     const int n_ot = dyp, n_xt = x1p + x2p;
-    // the final layer's workgroups also form the sigma head's gradient (same X: h8 read once; see mlp_bwd_dw_kernel): their tile
-    // carries the dY_sigma pair as its LAST piece and the section's scale in slot 3 of the wave's scale dwords
+    // the dir layer's workgroups also form the sigma head's gradient (same X section h8, read once; see mlp_bwd_dw_kernel): their tile
+    // carries the dY_sigma pair as its LAST piece and the section's scale in slot 3 of the wave's scale dwords; the waves 4..7 (the
+    // dir layer has 4 dY tiles) multiply it by the h8 tiles 2 (w - 4), 2 (w - 4) + 1
     const bool fold = jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid;
     const int np = dyp + n_xt + (fold ? 1 : 0);                // pieces per tile
     const int dy_pair0 = jb.dy_off / 2, x1_pair0 = jb.x1_off / 2, x2_pair0 = jb.x2_off / 2;
@@ -708,9 +698,8 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 
     f32x16 acc[kDwMaxXTiles];
     f32x16 accb;
-    f32x16 acc_sig, accb_sig;                                  // (folded sigma head)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = acc_sig[r] = accb_sig[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
 #pragma unroll
     for (int x = 0; x < kDwMaxXTiles; ++x)
 #pragma unroll
@@ -779,24 +768,12 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                 const i32x8 a = load_frag(st_base + wave * kPieceBytes);
                 const int sa = *reinterpret_cast<const int*>(sc_base);
                 const int sx1 = *reinterpret_cast<const int*>(sc_base + 4), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
-                [[maybe_unused]] i32x8 a_sg, b_sg;
-                [[maybe_unused]] int sa_sg = 0;
-                if constexpr (FOLD) {                                   // dY_sigma pair (the tile's last piece) and X tile `wave`
-                    a_sg = load_frag(st_base + (np - 1) * kPieceBytes);
-                    b_sg = load_frag(x_base + wave * kPieceBytes);
-                    sa_sg = *reinterpret_cast<const int*>(sc_base + 12);
-                }
                 i32x8 b[RD];
                 b[0] = load_frag(x_base);
                 if (NXT > 1) b[1] = load_frag(x_base + kPieceBytes);
                 __builtin_amdgcn_sched_barrier(0);
                 accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, 127);   // bias: dY x 1.0
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (FOLD) {
-                    acc_sig = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, b_sg, acc_sig, NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, sx1);
-                    accb_sig = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, ones, accb_sig, NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, 127);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
                 for (int x = 0; x < NXT; ++x) {
                     if (x + 2 < NXT) b[(x + 2) % RD] = load_frag(x_base + (x + 2) * kPieceBytes);
@@ -805,6 +782,30 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[x % RD], acc[x], NERFHIP_F8_DY_E5M2, 0, 0, sa, 0, x < x1p ? sx1 : sx2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            } else if constexpr (FOLD) {
+                // the folded sigma head: dY_sigma pair (the tile's last piece) x X pieces 1 + 2 (w - 4), 2 + 2 (w - 4) of the stage (piece
+                // 0 is enc_dir) into acc[0], acc[1]; wave 4 also forms the bias partial (dY_sigma x 1.0)
+                const char* st_base = ring + (it % DEPTH) * STAGE_BYTES + rd_off;
+                const char* sc_base = ring + DEPTH * STAGE_BYTES + ((it % DEPTH) * 8 + wave) * SCALE_BYTES + H * 64;
+                auto load_frag = [&](const char* pb) {
+                    i32x8 f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                            (__attribute__((address_space(3))) i32x2*)(pb + (q >> 1) * tile1 + (q & 1) * 256));
+                        f[2 * q] = v[0];
+                        f[2 * q + 1] = v[1];
+                    }
+                    return f;
+                };
+                const char* xs = st_base + (dyp + 1 + 2 * (wave - kDwFoldRow0)) * kPieceBytes;
+                const i32x8 a_sg = load_frag(st_base + (np - 1) * kPieceBytes);
+                const i32x8 b0 = load_frag(xs), b1 = load_frag(xs + kPieceBytes);
+                const int sa_sg = *reinterpret_cast<const int*>(sc_base + 12), sx2 = *reinterpret_cast<const int*>(sc_base + 8);
+                acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, b0, acc[0], NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, sx2);
+                acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, b1, acc[1], NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, sx2);
+                if (wave == kDwFoldRow0)
+                    accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_sg, ones, accb, NERFHIP_F8_DY_E5M2, 0, 0, sa_sg, 0, 127);
             }
 #if NERFHIP_DW_PROBE
             pr_comp += shader_cycles() - t3;
@@ -814,11 +815,11 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     switch (n_xt) {
         case 2: run(std::integral_constant<int, 2>{}, std::false_type{}); break;
         case 4: run(std::integral_constant<int, 4>{}, std::false_type{}); break;
-        case 8:
-            if (fold) run(std::integral_constant<int, 8>{}, std::true_type{});       // final layer + folded sigma head
-            else run(std::integral_constant<int, 8>{}, std::false_type{});
+        case 8: run(std::integral_constant<int, 8>{}, std::false_type{}); break;
+        case 9:
+            if (fold) run(std::integral_constant<int, 9>{}, std::true_type{});       // dir layer + folded sigma head
+            else run(std::integral_constant<int, 9>{}, std::false_type{});
             break;
-        case 9: run(std::integral_constant<int, 9>{}, std::false_type{}); break;
         default: run(std::integral_constant<int, 10>{}, std::false_type{}); break;          // 10 = kDwMaxXTiles (the skip layer)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain the look-ahead DMAs before exit
@@ -835,13 +836,14 @@ void mlp_bwd_dw_f8_kernel(DwJobTable jobs, float* __restrict__ slabs) {
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
         }
-        if (fold) {                              // the sigma head's (dY tile 0, X tile `wave`) partial: row `wave`, column kDwFoldCol
-            dw_store_block(slb + (size_t)(wave * kDwMaxXTiles + kDwFoldCol) * 1024, acc_sig, lane);
-            if (wave == 0 && (lane & 31) == 0) {
-                float* bdst = slb + (size_t)kDwFoldBiasCol * 64 * 16;
+    } else if (fold) {                           // the sigma head's partials: blocks dw_fold_block(2 (w - 4)), (.. + 1); bias row kDwFoldRow0
+        float* slb = slabs + (size_t)blockIdx.x * kDwSlabFloats;
+        dw_store_block(slb + (size_t)dw_fold_block(2 * (wave - kDwFoldRow0)) * 1024, acc[0], lane);
+        dw_store_block(slb + (size_t)dw_fold_block(2 * (wave - kDwFoldRow0) + 1) * 1024, acc[1], lane);
+        if (wave == kDwFoldRow0 && (lane & 31) == 0) {
+            float* bdst = slb + 8 * kDwMaxXTiles * 64 * 16 + kDwFoldRow0 * 64;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb_sig[rr];
-            }
+            for (int rr = 0; rr < 16; ++rr) bdst[(rr & 3) + 8 * (rr >> 2) + 4 * H] = accb[rr];
         }
     }
 #if NERFHIP_DW_PROBE
@@ -873,49 +875,64 @@ struct AdamFused {
     float lr, beta1, beta2, eps, wd;
 };
 
-// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients [and apply Adam].
-// One 256-thread block per (job, 32x32 tile): thread = one float4 (rows o..o+3 of one column) of the 1024-float
-// tile, summed over the job's splits with independent 16-B loads.
-// F8: operand rows/columns arrive in the order ds_read_b64_tr_b8 delivers them (m -> slab m >> 4, half (m >> 3) & 1, slot m & 7)
-// instead of natural feature order, and the bias partials hold one value per row.
-template <bool F8>
-__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, const float* __restrict__ slabs, GradTable G,
-                                                              int accumulate, AdamFused A) {
-    const int jid = blockIdx.y;
-    const DwJob jb = jobs.job[jid];
-    const int model = jid / kNumDwJobs;
-    const int fold = jobs.fold_of[jid];                 // >= 0: this job's partials live in job `fold`'s slabs (row = X tile, column kDwFoldCol)
-    const int nsplit = jobs.nsplit[fold >= 0 ? fold : jid], s0 = jobs.soff[fold >= 0 ? fold : jid];
-    const int n_ot = jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
-    const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
-    const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
-    const int ot = tile / (kDwMaxXTiles + 1), xt = tile % (kDwMaxXTiles + 1);
+// one gradient element: written (or accumulated) and, with Adam fused, applied
+struct GradEmit {
+    const AdamFused& A;
     AdamCoef ac;
-    if (A.state) ac = adam_coef(A.state[0] + 1.0f, A.lr, A.beta1, A.beta2);
-    auto emit = [&](float* dst, float val) {
+    int accumulate, model;
+    __device__ __forceinline__ void operator()(float* dst, float val) const {
         const float g = accumulate ? *dst + val : val;
         *dst = g;
         if (A.state) {
             const size_t e = (size_t)(dst - A.grad0[model]);
             adam_elem(A.param[model][e], g, A.m[model][e], A.v[model][e], ac, A.beta2, A.eps, A.wd);
         }
-    };
+    }
+};
+
+// sum split slabs, undo the fragment/feature permutation, write (out,in) row-major gradients [and apply Adam].
+// Columns of enc kDwEncFold (the dir job's h8 section) are the G matrix of the folded final layer, the dir job's bias sums its s:
+// both also go — plainly — to the model's fold scratch for mlp_bwd_fold_kernel; the final layer's own job has nothing here.
+// One 256-thread block per (job, 32x32 tile): thread = one float4 (rows o..o+3 of one column) of the 1024-float
+// tile, summed over the job's splits with independent 16-B loads.
+// F8: operand rows/columns arrive in the order ds_read_b64_tr_b8 delivers them (m -> slab m >> 4, half (m >> 3) & 1, slot m & 7)
+// instead of natural feature order, and the bias partials hold one value per row.
+template <bool F8>
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, const float* __restrict__ slabs, GradTable G,
+                                                              float* __restrict__ fold_scratch, int accumulate, AdamFused A) {
+    const int jid = blockIdx.y;
+    const DwJob jb = jobs.job[jid];
+    const int model = jid / kNumDwJobs;
+    const int fold = jobs.fold_of[jid];                 // >= 0: this job's partials live in job `fold`'s slabs (blocks dw_fold_block(X tile))
+    const int nsplit = jobs.nsplit[fold >= 0 ? fold : jid], s0 = jobs.soff[fold >= 0 ? fold : jid];
+    const bool derived = jid % kNumDwJobs == kDwJobFinal;              // finished by mlp_bwd_fold_kernel
+    const int n_ot = derived ? 0 : jb.dy_slabs / 2, n_xt = (jb.x1_slabs + jb.x2_slabs) / 2;
+    float* const scratch = fold_scratch + (size_t)model * kFoldScratchFloats;
+    const int n_out = kParamOut[jb.param], ldw = kParamIn[jb.param];
+    const int tile = blockIdx.x;                       // (ot, xt) pairs + one extra block per ot for the bias
+    const int ot = tile / (kDwMaxXTiles + 1), xt = tile % (kDwMaxXTiles + 1);
+    AdamCoef ac;
+    if (A.state) ac = adam_coef(A.state[0] + 1.0f, A.lr, A.beta1, A.beta2);
+    const GradEmit emit{A, ac, accumulate, model};
     if (ot < n_ot && xt == kDwMaxXTiles) {             // bias: lanes (m,0) + (m,1)
         const int m = threadIdx.x;
         if (m < 32) {
             float sacc = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) {
-                const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats +
-                                  (fold >= 0 ? (size_t)kDwFoldBiasCol * 64 * 16 : (size_t)8 * kDwMaxXTiles * 64 * 16 + ot * 64);
+                const float* sl = slabs + (size_t)(s0 + sp) * kDwSlabFloats + (size_t)8 * kDwMaxXTiles * 64 * 16 +
+                                  (fold >= 0 ? kDwFoldRow0 : ot) * 64;
                 sacc += F8 ? sl[m] : sl[m] + sl[m + 32];
             }
             const int o = F8 ? 32 * ot + chain_feature(m >> 4, f8_row_h(m & 15), f8_row_j(m & 15)) : 32 * ot + m;
-            if (o < n_out) emit(G.b[jid] + o, sacc);
+            if (o < n_out) {
+                emit(G.b[jid] + o, sacc);
+                if (jid % kNumDwJobs == kDwJobDir) scratch[kFoldS + o] = sacc;
+            }
         }
     } else if (ot < n_ot && xt < n_xt) {
         const int e4 = threadIdx.x;                    // float4 e4 of the block (dw_store_block: register-major): lane = e4 & 63, r = 4*(e4>>6)+k
         const float4* src = reinterpret_cast<const float4*>(slabs + (size_t)s0 * kDwSlabFloats +
-                                                            ((size_t)(fold >= 0 ? xt * kDwMaxXTiles + kDwFoldCol : ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
+                                                            ((size_t)(fold >= 0 ? dw_fold_block(xt) : ot * kDwMaxXTiles + xt) * 64) * 16) + e4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) {
@@ -935,12 +952,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
         if (xs < jb.x1_slabs) { enc = jb.x1_enc; col0 = jb.x1_col0; }
         else { xs -= jb.x1_slabs; enc = jb.x2_enc; col0 = jb.x2_col0; }
         int col;
-        if (enc == 0) col = col0 + chain_feature(xs, sh, sj);
+        if (enc == 0 || enc == kDwEncFold) col = col0 + chain_feature(xs, sh, sj);
         else {
             const int ch = (enc == 1) ? xyz_slot_channel(xs, sh, sj) : dir_slot_channel(xs, sh, sj);
             col = ch < 0 ? -1 : col0 + ch;
         }
-        if (col >= 0 && col < ldw) {
+        if (enc == kDwEncFold) {                           // G[o][h8 feature]: this call's sum, never accumulated, never an Adam input
+            const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (o0 + k < n_out) scratch[kFoldG + (size_t)(o0 + k) * kW + col] = vals[k];
+        } else if (col >= 0 && col < ldw) {
             const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -961,6 +983,85 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(DwJobTable jobs, co
                 A.state[0] = A.state[0] + 1.0f;
             }
         }
+    }
+}
+
+// ================================================================================================
+// Phase C: the folded final layer (mlp_layout.h kDwJobs)
+// ================================================================================================
+//     dW_dir[j][m]   = sum_k G[j][k] W_f[m][k] + s[j] b_f[m]      (j < 128, m < 256: the first 256 columns of dir_encoding's weight)
+//     dW_final[m][k] = sum_j W_dx[j][m] G[j][k]                    (m, k < 256)
+//     db_final[m]    = sum_j W_dx[j][m] s[j]
+// fp32 FMAs in a fixed order (2 x 8.4 M per model).  One 256-thread workgroup per 32 x 32 output tile, operands staged through LDS
+// in 32-deep slices: blocks 0..31 the dW_dir tiles, 32..95 the dW_final tiles, 96 the bias.  W_f, W_dx, b_f come from the fold
+// block of the packed W^T image — a snapshot taken before the step's update, so with Adam fused the update of one block cannot
+// reach the operands of another.
+struct FoldArgs {
+    const float* image[kDwMaxModels];      // fold block of the model's packed W^T image
+    float* gw_final[kDwMaxModels];
+    float* gb_final[kDwMaxModels];
+    float* gw_dir[kDwMaxModels];
+};
+constexpr int kFoldBlocks = 32 + 64 + 1;
+__global__ __launch_bounds__(256) void mlp_bwd_fold_kernel(FoldArgs F, const float* __restrict__ fold_scratch, int accumulate, AdamFused A) {
+    __shared__ float sa[32][33], sb[32][33];
+    const int model = blockIdx.y, bx = blockIdx.x, t = threadIdx.x;
+    const float* __restrict__ Gm = fold_scratch + (size_t)model * kFoldScratchFloats + kFoldG;
+    const float* __restrict__ sv = fold_scratch + (size_t)model * kFoldScratchFloats + kFoldS;
+    const float* __restrict__ Wf = F.image[model] + (size_t)kFoldWf * 256;
+    const float* __restrict__ Wdx = F.image[model] + (size_t)kFoldWdx * 256;
+    const float* __restrict__ bf = F.image[model] + (size_t)kFoldBf * 256;
+    AdamCoef ac;
+    if (A.state) ac = adam_coef(A.state[0], A.lr, A.beta1, A.beta2);          // (the reduce launch before this one advanced the counter)
+    const GradEmit emit{A, ac, accumulate, model};
+    const int c = t & 31, r0 = t >> 5;                    // thread = column c of rows r0, r0 + 8, r0 + 16, r0 + 24 of the tile
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bx < 32) {
+        const int j0 = 32 * (bx >> 3), m0 = 32 * (bx & 7);
+        for (int k0 = 0; k0 < 256; k0 += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[r0 + 8 * i][c] = Gm[(size_t)(j0 + r0 + 8 * i) * 256 + k0 + c];
+                sb[r0 + 8 * i][c] = Wf[(size_t)(m0 + r0 + 8 * i) * 256 + k0 + c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float b = sb[c][kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sa[r0 + 8 * i][kk], b, acc[i]);
+            }
+        }
+        const float bm = bf[m0 + c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = j0 + r0 + 8 * i;
+            emit(F.gw_dir[model] + (size_t)j * kParamIn[9] + m0 + c, __builtin_fmaf(sv[j], bm, acc[i]));
+        }
+    } else if (bx < 96) {
+        const int m0 = 32 * ((bx - 32) >> 3), k0 = 32 * ((bx - 32) & 7);
+        for (int j0 = 0; j0 < 128; j0 += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[r0 + 8 * i][c] = Wdx[(size_t)(j0 + r0 + 8 * i) * 256 + m0 + c];
+                sb[r0 + 8 * i][c] = Gm[(size_t)(j0 + r0 + 8 * i) * 256 + k0 + c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const float b = sb[jj][c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sa[jj][r0 + 8 * i], b, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) emit(F.gw_final[model] + (size_t)(m0 + r0 + 8 * i) * 256 + k0 + c, acc[i]);
+    } else {
+        float a = 0.f;
+        for (int j = 0; j < 128; ++j) a = __builtin_fmaf(Wdx[(size_t)j * 256 + t], sv[j], a);
+        emit(F.gb_final[model] + t, a);
     }
 }
 
@@ -1016,7 +1117,7 @@ extern "C" size_t nerfhip_mlp_dy_bytes(int64_t n_points, int dtype) {
 #define NERFHIP_DW_COST_B 45
 #endif
 #ifndef NERFHIP_DW_FOLD_SIGMA
-#define NERFHIP_DW_FOLD_SIGMA 1      // the final layer's workgroups also form the sigma head's gradient (same X: h8 read once)
+#define NERFHIP_DW_FOLD_SIGMA 1      // the dir layer's workgroups also form the sigma head's gradient (same X section: h8 read once)
 #endif
 #ifndef NERFHIP_DW_MIN_ITERS
 #define NERFHIP_DW_MIN_ITERS 48      // a workgroup should run at least this many ring iterations: the DEPTH-stage DMA pipeline
@@ -1048,14 +1149,16 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         // launch has not been re-measured.  NERFHIP_DW_COST_A / _B = a + b x KiB instead, for experiments)
         const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
         const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
-        const bool fold = NERFHIP_DW_FOLD_SIGMA;             // (bf16 since round 4; e4m3 and fp32 since round 5)
-        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs + (fold && j % kNumDwJobs == kDwJobFinal ? 2 : 0));
+        const bool fold = NERFHIP_DW_FOLD_SIGMA;             // (bf16 since round 4; e4m3 and fp32 since round 5; into the dir job since round 6)
+        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs + (fold && j % kNumDwJobs == kDwJobDir ? 2 : 0));
         if (cost[j] < 1) cost[j] = 1;
         units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
         cap[j] = NERFHIP_DW_MIN_ITERS > 0 ? units[j] / NERFHIP_DW_MIN_ITERS : units[j];
         if (cap[j] > units[j]) cap[j] = units[j];
         if (cap[j] < 1) cap[j] = 1;
-        if (fold && j % kNumDwJobs == kDwJobSigma) {       // the final layer's workgroups form dW_sigma too: no workgroups of its own
+        // no workgroups of their own: the final layer (derived from the dir job's G by mlp_bwd_fold_kernel, mlp_layout.h kDwJobs) and,
+        // folded, the sigma head (the dir layer's workgroups form dW_sigma too)
+        if (j % kNumDwJobs == kDwJobFinal || (fold && j % kNumDwJobs == kDwJobSigma)) {
             cap[j] = 0;
             ns[j] = 0;
             continue;
@@ -1073,7 +1176,7 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
             if (best < 0) { best = j; continue; }
             const int64_t a = units[j] * cost[j] * ns[best], b = units[best] * cost[best] * ns[j];   // time per workgroup of j vs best
             const int jj = j % kNumDwJobs, bb = best % kNumDwJobs;
-            const bool j_big = jj >= 1 && jj <= 8, b_big = bb >= 1 && bb <= 8;
+            const bool j_big = jj >= 1 && jj <= 7, b_big = bb >= 1 && bb <= 7;
             if (a > b || (a == b && j_big && !b_big)) best = j;
         }
         if (best < 0) break;
@@ -1088,7 +1191,7 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
             jt->nsplit[j] = j < njobs ? ns[j] : 0;
             jt->soff[j] = off;
             jt->ntiles[j] = act_tiles(n_points[jj / kNumDwJobs], dtype);
-            jt->fold_of[j] = (j < njobs && ns[j] == 0 && j % kNumDwJobs == kDwJobSigma) ? j - kDwJobSigma + kDwJobFinal : -1;
+            jt->fold_of[j] = (j < njobs && ns[j] == 0 && j % kNumDwJobs == kDwJobSigma) ? j - kDwJobSigma + kDwJobDir : -1;
             if (j < njobs) off += ns[j];
         }
         jt->soff[kDwMaxJobs] = off;
@@ -1101,14 +1204,19 @@ extern "C" int nerfhip_mlp_dw_splits(int64_t n_points, int dtype) {      // tota
     if (n_points <= 0 || !valid_dtype(dtype)) return 0;
     return dw_plan(&n_points, 1, dtype, nullptr);
 }
+// workspace = the launch's partial slabs, then one fold scratch (G, s) per model
+static size_t dw_workspace_bytes(int nwg, int n_models) {
+    return ((size_t)nwg * nerfhip::mlp::kDwSlabFloats + (size_t)n_models * nerfhip::mlp::kFoldScratchFloats) * sizeof(float);
+}
 extern "C" size_t nerfhip_mlp_dw_workspace_bytes(int64_t n_points, int dtype) {
-    return (size_t)nerfhip_mlp_dw_splits(n_points, dtype) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+    const int nwg = nerfhip_mlp_dw_splits(n_points, dtype);
+    return nwg > 0 ? dw_workspace_bytes(nwg, 1) : 0;
 }
 extern "C" size_t nerfhip_mlp_dw_workspace_bytes_multi(const int64_t* n_points_host, int n_models, int dtype) {
     if (!n_points_host || n_models < 1 || n_models > nerfhip::kDwMaxModels || !valid_dtype(dtype)) return 0;
     for (int m = 0; m < n_models; ++m)
         if (n_points_host[m] <= 0) return 0;
-    return (size_t)dw_plan(n_points_host, n_models, dtype, nullptr) * nerfhip::mlp::kDwSlabFloats * sizeof(float);
+    return dw_workspace_bytes(dw_plan(n_points_host, n_models, dtype, nullptr), n_models);
 }
 
 // The split plan itself (host logic, no GPU): splits_out[12 m + j] = workgroups of weight-gradient job j of model m, stage_kib_out
@@ -1123,7 +1231,7 @@ extern "C" int nerfhip_mlp_dw_plan(const int64_t* n_points_host, int n_models, i
         splits_out[j] = jt.nsplit[j];
         if (stage_kib_out) {
             int slabs = jt.job[j].dy_slabs + jt.job[j].x1_slabs + jt.job[j].x2_slabs;
-            if (jt.fold_of[j] >= 0) slabs = 0;                                        // folded into another job's stage
+            if (jt.fold_of[j] >= 0 || jt.nsplit[j] == 0) slabs = 0;                   // folded into another job's stage / derived
             for (int k = 0; k < n_models * nerfhip::mlp::kNumDwJobs; ++k)
                 if (jt.fold_of[k] == j) slabs += jt.job[k].dy_slabs;
             stage_kib_out[j] = dtype == NERFHIP_F32 ? 2 * slabs : slabs;            // (the e4m3 kernel moves TWO tiles of slabs / 2 KiB each)
@@ -1151,6 +1259,16 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
             return NERFHIP_E_ALIGN;
     }
     const int nwg = dw_plan(n_host, n_models, dtype, &jt);
+    float* const fold_scratch = (float*)dw_workspace + (size_t)nwg * nerfhip::mlp::kDwSlabFloats;
+    nerfhip::FoldArgs F;
+    for (int m = 0; m < nerfhip::kDwMaxModels; ++m) {
+        const int mm = m < n_models ? m : 0;
+        F.image[m] = reinterpret_cast<const float*>((const uint8_t*)packed_bwd_host[mm] +
+                                                    (size_t)nerfhip::mlp::bwd_padded_pieces(compute_prec(dtype)) * nerfhip::mlp::kPieceBytes);
+        F.gw_final[m] = grad_w_host[12 * mm + 8];
+        F.gb_final[m] = grad_b_host[12 * mm + 8];
+        F.gw_dir[m] = grad_w_host[12 * mm + 9];
+    }
     for (int j = 0; j < nerfhip::kDwMaxJobs; ++j) {
         const int jj = j < jt.njobs ? j : 0, m = jj / nerfhip::mlp::kNumDwJobs, prm = nerfhip::mlp::kDwJobs[jj % nerfhip::mlp::kNumDwJobs].param;
         NERFHIP_CHECK_ARG(grad_w_host[12 * m + prm] && grad_b_host[12 * m + prm]);
@@ -1189,9 +1307,13 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
     }
     if (do_reduce) {
         if (dtype == NERFHIP_BF16_F8)
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate, A);
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, fold_scratch,
+                               accumulate, A);
         else
-            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, accumulate, A);
+            hipLaunchKernelGGL(nerfhip::mlp_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, s, jt, (const float*)dw_workspace, G, fold_scratch,
+                               accumulate, A);
+        hipLaunchKernelGGL(nerfhip::mlp_bwd_fold_kernel, dim3(nerfhip::kFoldBlocks, (unsigned)n_models), dim3(256), 0, s, F,
+                           (const float*)fold_scratch, accumulate, A);
     }
     return nerfhip_launch_status();
 }

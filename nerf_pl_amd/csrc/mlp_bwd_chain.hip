@@ -348,7 +348,7 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
             mk_slab(out[2 * t + sl], v8);
         }
         }
-        if constexpr (!F8) {
+        if constexpr (!F8 && L != kBwdLayerDir) {       // (dL/d(final), the dir^T layer's output, is not stored: mlp_layout.h kDwJobs)
             // per-layer descriptor: the (possibly runtime, wave-uniform) section offset sits in its SALU-computed base, the
             // per-tile offsets are immediates (soffset stays 0: gfx950 store-data hazard, see store_slab)
             __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab) * act_il(PREC), 0,
@@ -484,13 +484,13 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
     Slab g_in0[1] = {g_rgb};
     int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, lds_lo, lds_hi, sig_lds, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
                                                           f8_dy_section(kDyDir), -1, 127, lane);
-    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga   (F8: stores its input dY_dir)
+    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga, registers only   (F8: stores its input dY_dir)
     sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, lds_lo, lds_hi, sig_lds, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, f8_dy_section(kDyFeat),
                                                        kDyDir, sb, lane);
     // (the sigma head's slab is the 17th K slab of the next layer: parked in LDS, see run_bwd_layer_tm)
     *reinterpret_cast<__attribute__((address_space(3))) Slab*>(sig_lds) = g_sig;
-    // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (F8: stores dY_feat)
-    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 8>(st, lds_lo, lds_hi, sig_lds, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
+    // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (its input dY_feat is stored in no mode: mlp_layout.h kDwJobs)
+    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 0>(st, lds_lo, lds_hi, sig_lds, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
                                                        f8_dy_section(dy_h(8)), kDyFeat, sb, lane);
     // ---- layers 3..8 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
     // straight-line code against a 64 KiB instruction cache (profiles/archive/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel

@@ -274,9 +274,11 @@ NH_HD constexpr int pend_kind(int PL) {
 // saved-activation section / gate piece of a layer's OUTPUT; section a layer stores in the fp8 mode (its chain INPUT)
 NH_HD constexpr int layer_out_sec(int L) { return L <= 7 ? act_h(L + 1) : (L == 9 ? kActFeat : (L == 10 ? kActT : -1)); }
 NH_HD constexpr int layer_gate_piece(int L) { return L <= 7 ? mask_piece_h(L + 1) : (L == 10 ? kMaskPieceT : -1); }
-NH_HD constexpr int layer_in_sec(int L) {
-    return (L >= 1 && L <= 7) ? act_h(L) : (L == 9 ? act_h(8) : (L == 10 ? kActFeat : (L == 11 ? kActT : -1)));
+NH_HD constexpr int layer_in_sec(int L) {       // (the dir layer's input f = xyz_encoding_final's output is not saved: mlp_layout.h kDwJobs)
+    return (L >= 1 && L <= 7) ? act_h(L) : (L == 9 ? act_h(8) : (L == 11 ? kActT : -1));
 }
+// sections the activation-saving forward writes (everything but f, which no weight-gradient job reads)
+NH_HD constexpr bool layer_out_saved(int L) { return layer_out_sec(L) >= 0 && layer_out_sec(L) != kActFeat; }
 
 #ifndef NERFHIP_EXP_NOPS
 #define NERFHIP_EXP_NOPS 0
@@ -364,7 +366,7 @@ __device__ __forceinline__ void epi_piece(Ctx& cx, St& st, const f32x16& c, Slab
         const int lane = fresh_lane();
         // NERFHIP_SAVE_BURST slabs per run of back-to-back stores (1 = each slab as soon as it is packed; a layer's slabs stay in
         // registers as the next layer's operands, so holding a run back costs no register)
-        if (!F8 && (p & 3) == 3) {
+        if (!F8 && layer_out_saved(PL) && (p & 3) == 3) {
             const int si = 2 * pt + (p >> 2);
             if ((si + 1) % NERFHIP_SAVE_BURST == 0)
                 save_slabs(st, cx.tile, layer_out_sec(PL) + si + 1 - NERFHIP_SAVE_BURST, &po[si + 1 - NERFHIP_SAVE_BURST], NERFHIP_SAVE_BURST, lane);

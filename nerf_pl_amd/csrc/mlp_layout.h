@@ -170,7 +170,7 @@ constexpr int kActEncX = 0;                 // 4 slabs  xyz encoding (slot order
 constexpr int kActEncD = 4;                 // 2 slabs  dir encoding
 constexpr int kActH0 = 6;                   // h1..h8: 8 x 16 slabs (post-ReLU)
 NH_HD constexpr int act_h(int l) { return kActH0 + 16 * (l - 1); }   // l = 1..8
-constexpr int kActFeat = kActH0 + 128;      // 16 slabs  xyz_encoding_final output (no activation)
+constexpr int kActFeat = kActH0 + 128;      // 16 slabs  xyz_encoding_final output (no activation): NOT saved since round 6 (see kDwJobs); the slots stay
 constexpr int kActT = kActFeat + 16;        // 8 slabs   dir_encoding output (post-ReLU)
 constexpr int kActSlabs = kActT + 8;        // 158
 // ReLU gates: after the slabs of a tile, one 1 KiB piece per gated layer (h1..h8, t): a lane's 16 B are four words, word w
@@ -214,7 +214,7 @@ NH_HD inline size_t tile_block_off(long long tile, int tile_bytes, int il) {
 // Backward chain writes dL/d(pre-activation) slabs in the same format.
 constexpr int kDyRgb = 0;                   // 2 slabs (3 real features, rest zero)
 constexpr int kDyDir = 2;                   // 8 slabs
-constexpr int kDyFeat = 10;                 // 16 slabs
+constexpr int kDyFeat = 10;                 // 16 slabs: dL/d(final) is NOT stored since round 6 (see kDwJobs); the slots stay
 constexpr int kDySigma = 26;                // 2 slabs (1 real feature)
 constexpr int kDyH0 = 28;                   // dY_8 .. dY_1: 8 x 16 slabs
 NH_HD constexpr int dy_h(int l) { return kDyH0 + 16 * (8 - l); }     // l = 1..8
@@ -229,6 +229,7 @@ struct BwdLayer {
     int sigma_slab; // 1: the last slab is the sigma-head slab (W_sigma row 0 at slot h=0,j=0)
 };
 constexpr int kNumBwdLayers = 10;
+constexpr int kBwdLayerDir = 1;            // index (in the table below) of dir^T, whose output dL/d(final) stays in registers
 constexpr BwdLayer kBwdLayers[kNumBwdLayers] = {
     {11, 4, 1, 0, 0},    // rgb^T      : g_a_rgb(3)   -> g_t(128)
     {9, 8, 8, 0, 0},     // dir^T      : g_a_dir(128) -> g_feat(256)       (feat columns 0..255 of W_dir)
@@ -260,7 +261,18 @@ NH_HD constexpr int bwd_chunks(int prec) { return bwd_padded_pieces(prec) / kChu
 // ---- weight-gradient jobs: dW[o][i] = sum_p dY[p][o] * X[p][i] ------------------------------------
 // One job = one (dY section, X sections) pair; a workgroup's wave w owns output tile w (32 dY features)
 // against all X tiles.  X = [x1 | x2] slabs (x2 may be empty); columns map back to the reference
-// weight matrix through (x?_col0, x?_enc): enc 0 = chain features (natural), 1 = xyz slots, 2 = dir slots.
+// weight matrix through (x?_col0, x?_enc): enc 0 = chain features (natural), 1 = xyz slots, 2 = dir slots,
+// 3 = chain features of the fold scratch (below).
+//
+// The linear layer folded out of the saved tensors (round 6).  xyz_encoding_final has NO activation (nerf.py:70,116):
+//     f = W_f h8 + b_f,   u = W_dx f + W_dd enc_d + b_d   (dir_encoding's pre-activation, W_dir = [W_dx | W_dd], nerf.py:118)
+// so with  G = sum_p dY_dir[p] h8[p]^T  (128 x 256)  and  s = sum_p dY_dir[p] = db_dir  (128):
+//     dW_dx = sum_p dY_dir f^T = G W_f^T + s b_f^T        dW_f = sum_p (W_dx^T dY_dir) h8^T = W_dx^T G        db_f = W_dx^T s
+// Neither f (16 slabs of X per tile) nor dL/df (16 slabs of dY) is needed by the weight-gradient launch: the forward does not
+// save f, the chain does not store dL/df (it still forms it in registers for g_h8), the dir job multiplies dY_dir by h8 instead of
+// f — the same job class — and mlp_bwd_fold_kernel finishes the three gradients from G, s and an fp32 snapshot of W_f, W_dx, b_f
+// (the fold block at the end of the packed W^T image).  10 % fewer saved bytes written and read per point, 11 % fewer dW FLOPs.
+// Job kDwJobFinal keeps its table entry (parameter mapping) but has no workgroups and nothing in the reduce kernel.
 struct DwJob {
     int param;
     int dy_off, dy_slabs;       // section in the dY block (slabs)
@@ -268,6 +280,8 @@ struct DwJob {
     int x2_off, x2_slabs, x2_col0, x2_enc;
 };
 constexpr int kNumDwJobs = 12;
+constexpr int kDwJobFinal = 8, kDwJobDir = 9, kDwJobSigma = 10;      // indices in kDwJobs
+constexpr int kDwEncFold = 3;
 constexpr DwJob kDwJobs[kNumDwJobs] = {
     {0, dy_h(1), 16, kActEncX, 4, 0, 1, 0, 0, 0, 0},                 // xyz_encoding_1 : X = enc_xyz
     {1, dy_h(2), 16, act_h(1), 16, 0, 0, 0, 0, 0, 0},
@@ -277,11 +291,20 @@ constexpr DwJob kDwJobs[kNumDwJobs] = {
     {5, dy_h(6), 16, act_h(5), 16, 0, 0, 0, 0, 0, 0},
     {6, dy_h(7), 16, act_h(6), 16, 0, 0, 0, 0, 0, 0},
     {7, dy_h(8), 16, act_h(7), 16, 0, 0, 0, 0, 0, 0},
-    {8, kDyFeat, 16, act_h(8), 16, 0, 0, 0, 0, 0, 0},                // xyz_encoding_final
-    {9, kDyDir, 8, kActEncD, 2, 256, 2, kActFeat, 16, 0, 0},         // dir_encoding: [enc_dir | feat]
+    {8, kDyFeat, 16, act_h(8), 16, 0, 0, 0, 0, 0, 0},                // xyz_encoding_final: DERIVED (mlp_bwd_fold_kernel), no workgroups
+    {9, kDyDir, 8, kActEncD, 2, 256, 2, act_h(8), 16, 0, kDwEncFold},   // dir_encoding: [enc_dir | h8] -> [dW_dd | G]
     {10, kDySigma, 2, act_h(8), 16, 0, 0, 0, 0, 0, 0},               // sigma
     {11, kDyRgb, 2, kActT, 8, 0, 0, 0, 0, 0, 0},                     // rgb
 };
+// fold scratch of one model (fp32, behind the launch's partial slabs in the dW workspace): G[128][256] then s[128]
+constexpr int kFoldG = 0, kFoldS = 128 * kW;
+constexpr int kFoldScratchFloats = kFoldS + 128;
+// fold block of the packed W^T image (fp32 pieces of 256 floats behind bwd_padded_pieces): W_f rows, W_dx rows, b_f
+constexpr int kFoldWf = 0;                  // 256 pieces: piece m = W_f[m][0..255]
+constexpr int kFoldWdx = 256;               // 128 pieces: piece j = W_dir[j][0..255]
+constexpr int kFoldBf = 384;                // 1 piece:    b_f[0..255]
+constexpr int kFoldPieces = 385;
+NH_HD constexpr int bwd_image_pieces(int prec) { return bwd_padded_pieces(prec) + kFoldPieces; }
 constexpr int kDwMaxXTiles = 10;            // (4+16)/2
 // fp32 partial-sum slab of one (job, split): [8 o-tiles][10 x-tiles][64 lanes][16] weights + [8][64] bias
 constexpr int kDwSlabFloats = 8 * kDwMaxXTiles * 64 * 16 + 8 * 64;

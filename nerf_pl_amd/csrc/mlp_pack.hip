@@ -56,7 +56,7 @@ extern "C" size_t nerfhip_mlp_packed_bytes(int dtype) {
 extern "C" size_t nerfhip_mlp_packed_bwd_bytes(int dtype) {
     dtype = nerfhip::pack_prec(dtype);
     if (dtype < 0) return 0;
-    return (size_t)nerfhip::mlp::bwd_padded_pieces(dtype) * nerfhip::mlp::kPieceBytes;
+    return (size_t)nerfhip::mlp::bwd_image_pieces(dtype) * nerfhip::mlp::kPieceBytes;     // W^T stream + fp32 fold block
 }
 
 extern "C" int nerfhip_mlp_pack_weights(const float* const* weights_host, const float* const* biases_host,
@@ -81,19 +81,19 @@ extern "C" int nerfhip_mlp_pack_weights(const float* const* weights_host, const 
     return nerfhip_launch_status();
 }
 
-extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, void* packed_bwd, int dtype,
-                                            nerfhip_stream_t stream) {
-    NERFHIP_CHECK_ARG(weights_host && packed_bwd);
+extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, const float* const* biases_host, void* packed_bwd,
+                                            int dtype, nerfhip_stream_t stream) {
+    NERFHIP_CHECK_ARG(weights_host && biases_host && packed_bwd);
     dtype = nerfhip::pack_prec(dtype);
     if (dtype < 0) return NERFHIP_E_UNSUPPORTED;
     if (((uintptr_t)packed_bwd) & 15) return NERFHIP_E_ALIGN;
     nerfhip::ParamTable P;
     for (int i = 0; i < 12; ++i) {
-        NERFHIP_CHECK_ARG(weights_host[i]);
+        NERFHIP_CHECK_ARG(weights_host[i] && biases_host[i]);
         P.w[i] = weights_host[i];
-        P.b[i] = nullptr;
+        P.b[i] = biases_host[i];
     }
-    const int n = nerfhip::mlp::bwd_padded_pieces(dtype);
+    const int n = nerfhip::mlp::bwd_image_pieces(dtype);
     if (dtype == NERFHIP_BF16)
         hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
     else
@@ -113,7 +113,7 @@ extern "C" int nerfhip_mlp_pack_weights_train(const float* const* weights_host, 
         P.w[i] = weights_host[i];
         P.b[i] = biases_host[i];
     }
-    const int n = nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_padded_pieces(dtype);
+    const int n = nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype);
     if (dtype == NERFHIP_BF16)
         hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed, (uint8_t*)packed_bwd);
@@ -143,7 +143,7 @@ extern "C" int nerfhip_mlp_pack_weights_train_multi(const float* const* weights_
             T.P[m].b[i] = biases_host[12 * mm + i];
         }
     }
-    const dim3 grid((unsigned)(nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_padded_pieces(dtype)), (unsigned)n_models);
+    const dim3 grid((unsigned)(nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype)), (unsigned)n_models);
     if (dtype == NERFHIP_BF16)
         hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_BF16>, grid, dim3(64), 0, (hipStream_t)stream, T);
     else

@@ -1,6 +1,7 @@
 // One 1 KiB piece of the packed weight streams (layout: mlp_layout.h), shared by the pack kernels of mlp_pack.hip:
 //   pack_fwd_piece: the forward's A-fragment stream (bias piece + (tile, slab) fragments per layer, execution order)
-//   pack_bwd_piece: the backward chain's W^T stream
+//   pack_bwd_piece: the backward chain's W^T stream, followed by the fp32 fold block (mlp_layout.h kFold*: W_f, W_dx, b_f as
+//                   mlp_bwd_fold_kernel reads them)
 #pragma once
 #include "common.h"
 #include "mlp_layout.h"
@@ -77,7 +78,14 @@ __device__ __forceinline__ uint4 pack_bwd_piece(const ParamTable& P, int g, int 
     using namespace mlp;
     const int m = lane & 31, h = lane >> 5;
     uint4 outv = make_uint4(0, 0, 0, 0);
-    if (g < bwd_total_pieces(PREC)) {
+    if (g >= bwd_padded_pieces(PREC)) {                             // fold block: plain fp32 rows, lane l = floats 4l .. 4l+3
+        const int q = g - bwd_padded_pieces(PREC);
+        const float* src = q < kFoldWdx ? P.w[8] + (size_t)(q - kFoldWf) * kParamIn[8]
+                                        : (q < kFoldBf ? P.w[9] + (size_t)(q - kFoldWdx) * kParamIn[9] : P.b[8]);
+        if (q < kFoldPieces)           // (W_dir rows are 283 floats: not 16-byte aligned, scalar loads)
+            outv = make_uint4(__float_as_uint(src[4 * lane]), __float_as_uint(src[4 * lane + 1]), __float_as_uint(src[4 * lane + 2]),
+                              __float_as_uint(src[4 * lane + 3]));
+    } else if (g < bwd_total_pieces(PREC)) {
         int L = 0, start = 0;
         while (L + 1 < kNumBwdLayers && g >= start + bwd_layer_pieces(L, PREC)) { start += bwd_layer_pieces(L, PREC); ++L; }
         const BwdLayer ly = kBwdLayers[L];

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(DrawTable T, unsign
         philox_draws_block(T, seed_v, offset_v, state, (int)blockIdx.x, draw_blocks);
         return;
     }
-    const int nf = mlp::padded_pieces(PREC), nb = mlp::bwd_padded_pieces(PREC);
+    const int nf = mlp::padded_pieces(PREC), nb = mlp::bwd_image_pieces(PREC);
     const int lane = threadIdx.x & 63;
     // one 1 KiB piece per wave, over (model, forward | W^T piece).  The piece index is wave-uniform and SAID to be so (readfirstlane):
     // the model's tables are then read straight from the kernel arguments with scalar loads, as in mlp_pack_train_multi_kernel.
@@ -62,7 +62,7 @@ extern "C" int nerfhip_train_prologue(const nerfhip_draw* draws_host, int n_draw
             P.P[m].b[i] = biases_host[12 * mm + i];
         }
     }
-    const int pieces = n_models * (nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_padded_pieces(dtype));
+    const int pieces = n_models * (nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype));
     const dim3 grid((unsigned)(draw_blocks + (pieces + 3) / 4));
     if (dtype == NERFHIP_BF16)
         hipLaunchKernelGGL(nerfhip::train_prologue_kernel<NERFHIP_BF16>, grid, dim3(256), 0, (hipStream_t)stream, T, (unsigned long long)seed,

@@ -137,11 +137,11 @@ class NeRF(nn.Module):
         return buf
 
     def packed_weights_bwd(self, dtype=None):
-        """W^T stream for the backward chain (same policy as packed_weights)."""
+        """W^T stream for the backward chain + the fp32 fold block (same policy as packed_weights)."""
         dtype = dtype or self.mlp_dtype
-        wp, _, dev = self._pack_args()
+        wp, bp, dev = self._pack_args()
         buf = self._bwd_buffer(dtype, dev)
-        ops.pack_weights_bwd_raw(wp, buf, dtype)
+        ops.pack_weights_bwd_raw(wp, bp, buf, dtype)
         return buf
 
     def train_buffers(self, dtype, dev):

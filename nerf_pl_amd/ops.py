@@ -485,8 +485,8 @@ def pack_weights_raw(wp, bp, out, dtype):
 
 
 @device_guard
-def pack_weights_bwd_raw(wp, out, dtype):
-    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), mlp_dtype_code(dtype), stream_ptr()),
+def pack_weights_bwd_raw(wp, bp, out, dtype):
+    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, bp, ptr(out), mlp_dtype_code(dtype), stream_ptr()),
           "nerfhip_mlp_pack_weights_bwd")
 
 
@@ -666,16 +666,18 @@ def render_train_fwd(rays, target, grad_scale, n_samples, n_importance, packed_c
 
 # ------------------------------------------------------------------------------- MLP backward (K2b)
 @device_guard
-def pack_weights_bwd(weights, dtype, out=None):
-    """W^T A-fragment stream for the backward chain (12 weights, state_dict order)."""
+def pack_weights_bwd(weights, biases, dtype, out=None):
+    """W^T A-fragment stream for the backward chain + the fp32 fold block (12 weights, 12 biases, state_dict order)."""
     code = mlp_dtype_code(dtype)
     keep = [_c(w.detach()) for w in weights]
-    for w in keep:
+    keep_b = [_c(b.detach()) for b in biases]
+    for w in keep + keep_b:
         require_gpu(w)
     if out is None:
         out = torch.empty(int(_lib.load().nerfhip_mlp_packed_bwd_bytes(code)), device=keep[0].device, dtype=torch.uint8)
     wp = (ctypes.c_void_p * 12)(*[k.data_ptr() for k in keep])
-    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, ptr(out), code, stream_ptr()), "nerfhip_mlp_pack_weights_bwd")
+    bp = (ctypes.c_void_p * 12)(*[k.data_ptr() for k in keep_b])
+    check(_lib.load().nerfhip_mlp_pack_weights_bwd(wp, bp, ptr(out), code, stream_ptr()), "nerfhip_mlp_pack_weights_bwd")
     return out
 
 

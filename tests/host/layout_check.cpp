@@ -102,7 +102,9 @@ int main() {
             CHECK(f8_dy_section(dy_h(l)) == 4 + (8 - l) && f8_dy_section(dy_h(l) + 15) == 4 + (8 - l), "dy section of dY_%d", l);
         }
     }
-    // ---- weight-gradient jobs: every parameter once, its X columns cover the input features exactly once ----
+    // ---- weight-gradient jobs: every parameter once, its X columns cover the input features exactly once.  The dir job's second X
+    // section is h8, not the final layer's output f (round 6: f is not saved): its 256 columns are the rows of G, which
+    // mlp_bwd_fold_kernel turns into dW_dir[:, 0..255] = G W_f^T + s b_f^T — they stand for those 256 input columns ----
     {
         std::set<int> params;
         for (int j = 0; j < kNumDwJobs; ++j) {
@@ -116,7 +118,7 @@ int main() {
                 for (int ks = 0; ks < slabs; ++ks)
                     for (int h = 0; h < 2; ++h)
                         for (int jj = 0; jj < 8; ++jj) {
-                            int c = enc == 0 ? chain_feature(ks, h, jj) : enc == 1 ? xyz_slot_channel(ks, h, jj) : dir_slot_channel(ks, h, jj);
+                            int c = (enc == 0 || enc == kDwEncFold) ? chain_feature(ks, h, jj) : enc == 1 ? xyz_slot_channel(ks, h, jj) : dir_slot_channel(ks, h, jj);
                             if (c < 0) continue;
                             c += col0;
                             if (c < in_features) ++hits[c];
@@ -126,6 +128,17 @@ int main() {
             CHECK((jb.x1_slabs + jb.x2_slabs) / 2 <= kDwMaxXTiles, "job %d X tiles", j);
         }
         CHECK((int)params.size() == 12, "jobs cover %d parameters", (int)params.size());
+        CHECK(kDwJobs[kDwJobDir].x2_enc == kDwEncFold && kDwJobs[kDwJobDir].x2_off == act_h(8) && kDwJobs[kDwJobDir].x2_col0 == 0,
+              "the dir job multiplies dY_dir by h8 (fold)");
+        // no job reads the sections that are no longer written
+        for (int j = 0; j < kNumDwJobs; ++j) {
+            if (j == kDwJobFinal) continue;                    // derived: no workgroups
+            const DwJob jb = kDwJobs[j];
+            CHECK(jb.dy_off + jb.dy_slabs <= kDyFeat || jb.dy_off >= kDyFeat + 16, "job %d reads dL/d(final)", j);
+            CHECK(jb.x1_off + jb.x1_slabs <= kActFeat || jb.x1_off >= kActFeat + 16, "job %d reads f (x1)", j);
+            CHECK(jb.x2_slabs == 0 || jb.x2_off + jb.x2_slabs <= kActFeat || jb.x2_off >= kActFeat + 16, "job %d reads f (x2)", j);
+        }
+        CHECK(kFoldScratchFloats == 128 * 256 + 128 && kFoldPieces == 256 + 128 + 1, "fold scratch / image block sizes");
     }
     // ---- backward chain stream ----
     for (int prec = 0; prec < 2; ++prec) {

@@ -6,7 +6,8 @@ import ctypes
 import pytest
 
 F32, BF16, BF16_F8 = 0, 1, 2
-STAGE_KIB = [20, 32, 32, 32, 36, 32, 32, 32, 32, 26, 18, 10]        # dY + X slabs of a 32-point tile, per job (mlp_layout.h kDwJobs)
+STAGE_KIB = [20, 32, 32, 32, 36, 32, 32, 32, 0, 28, 0, 10]          # dY + X slabs of a 32-point tile, per job (mlp_layout.h kDwJobs)
+FINAL, DIR, SIGMA = 8, 9, 10                                        # jobs without workgroups: the final layer (derived), the sigma head (folded)
 
 
 @pytest.fixture(scope="module")
@@ -27,14 +28,15 @@ def _plan(lib, points, dtype):
 
 def test_benchmark_step_is_one_round_of_the_256_cus(lib):
     """configs[2]: fine 1024 x 192 + coarse 1024 x 64 points in ONE launch."""
-    # The sigma head (job 10) has no workgroups of its own — the final layer's (job 8) form its gradient from the same h8 stage, which
-    # grows by the 2 dY_sigma slabs (bf16: round 4 — h8 used to be read twice, 5 % of the launch's bytes; e4m3 and fp32: round 5)
+    # Round 6: xyz_encoding_final (job 8) has no workgroups at all — it is a linear layer without activation, its gradients are
+    # finished from the dir job's G = dY_dir^T h8 by mlp_bwd_fold_kernel (mlp_layout.h kDwJobs) — and the sigma head (job 10) none of
+    # its own: the dir layer's workgroups (job 9) form its gradient from the h8 stage they now hold, which grows by the 2 dY_sigma slabs.
     for dtype, want, unit in ((BF16_F8, 256, 1), (BF16, 256, 1), (F32, 512, 2)):
         total, sp, kb = _plan(lib, [1024 * 192, 1024 * 64], dtype)
         assert total == want == sum(sp)
-        assert sp[10] == 0 == sp[22] and min(s for j, s in enumerate(sp) if j % 12 != 10) >= 1
-        assert kb[8] == 34 * unit == kb[20] and kb[10] == 0 == kb[22]
-        assert [k for j, k in enumerate(kb) if j % 12 not in (8, 10)] == [unit * k for j, k in enumerate(STAGE_KIB * 2) if j % 12 not in (8, 10)]
+        assert all(sp[12 * m + j] == 0 for m in (0, 1) for j in (FINAL, SIGMA))
+        assert min(s for j, s in enumerate(sp) if j % 12 not in (FINAL, SIGMA)) >= 1
+        assert kb == [unit * k for k in STAGE_KIB * 2]
 
 
 def iter_cost(kib):
@@ -70,14 +72,15 @@ def test_bf16_plan_equalises_time_not_iterations(lib):
 def test_small_and_ragged_sizes(lib):
     # fewer than 48 ring iterations per workgroup are never planned: a tiny batch gets one workgroup per job
     total, sp, _ = _plan(lib, [100], BF16)
-    assert total == 11 and sp == [1] * 10 + [0, 1]
+    assert total == 10 and sp == [1] * 8 + [0, 1, 0, 1]
     total, sp, _ = _plan(lib, [100], BF16_F8)
-    assert total == 11 and sp == [1] * 10 + [0, 1]
+    assert total == 10 and sp == [1] * 8 + [0, 1, 0, 1]
     total, sp, _ = _plan(lib, [32 * 48 * 3 + 5], BF16)       # (padded to whole 256-point blocks)
-    assert all(1 <= s <= 3 for j, s in enumerate(sp) if j != 10) and sp[10] == 0, sp
+    assert all(1 <= s <= 3 for j, s in enumerate(sp) if j not in (FINAL, SIGMA)) and sp[FINAL] == 0 == sp[SIGMA], sp
     # one model with the benchmark's fine pass alone
     total, sp, _ = _plan(lib, [1024 * 192], BF16_F8)
-    assert total == 256 and sp[10] == 0 and max(sp) - min(s for j, s in enumerate(sp) if j != 10) <= 1
+    live = [s for j, s in enumerate(sp) if j not in (FINAL, SIGMA)]
+    assert total == 256 and sp[FINAL] == 0 == sp[SIGMA] and max(live) - min(live) <= 1
 
 
 def test_bad_arguments(lib):
