@@ -1003,9 +1003,17 @@ struct FoldArgs {
     float* gw_dir[kDwMaxModels];
 };
 constexpr int kFoldBlocks = 32 + 64 + 1;
+// Latency, not arithmetic, is what this launch costs (it sits between the reduce and the optimizer): a workgroup fetches BOTH
+// operands of its tile whole — one round trip to L2 / HBM — and only then multiplies out of LDS, on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: an fmaf chain per output, as in the fp32 kernels), each of its 4 waves over a quarter of the inner
+// dimension; the four partial tiles are summed in a fixed order.  (First version: 32-deep slices, eight dependent round trips, 15 us
+// in the step; second: one round trip and a VALU loop bound by its LDS reads, ~6 us.)
 __global__ __launch_bounds__(256) void mlp_bwd_fold_kernel(FoldArgs F, const float* __restrict__ fold_scratch, int accumulate, AdamFused A) {
-    __shared__ float sa[32][33], sb[32][33];
+    constexpr int PA = 257, PB = 33;                      // LDS row pitches (floats): conflict-free reads
+    __shared__ float lds[2 * 32 * PA];
+    __shared__ float part[4][16][64];
     const int model = blockIdx.y, bx = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     const float* __restrict__ Gm = fold_scratch + (size_t)model * kFoldScratchFloats + kFoldG;
     const float* __restrict__ sv = fold_scratch + (size_t)model * kFoldScratchFloats + kFoldS;
     const float* __restrict__ Wf = F.image[model] + (size_t)kFoldWf * 256;
@@ -1014,54 +1022,78 @@ __global__ __launch_bounds__(256) void mlp_bwd_fold_kernel(FoldArgs F, const flo
     AdamCoef ac;
     if (A.state) ac = adam_coef(A.state[0], A.lr, A.beta1, A.beta2);          // (the reduce launch before this one advanced the counter)
     const GradEmit emit{A, ac, accumulate, model};
-    const int c = t & 31, r0 = t >> 5;                    // thread = column c of rows r0, r0 + 8, r0 + 16, r0 + 24 of the tile
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bx < 32) {
-        const int j0 = 32 * (bx >> 3), m0 = 32 * (bx & 7);
-        for (int k0 = 0; k0 < 256; k0 += 32) {
-            __syncthreads();
+    if (bx == kFoldBlocks - 1) {
+        // db_final[t] = sum_j W_dx[j][t] s[j]: four partial chains, the loads independent
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int j = 0; j < 128; j += 4)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sa[r0 + 8 * i][c] = Gm[(size_t)(j0 + r0 + 8 * i) * 256 + k0 + c];
-                sb[r0 + 8 * i][c] = Wf[(size_t)(m0 + r0 + 8 * i) * 256 + k0 + c];
-            }
-            __syncthreads();
+            for (int q = 0; q < 4; ++q) a4[q] = __builtin_fmaf(Wdx[(size_t)(j + q) * 256 + t], sv[j + q], a4[q]);
+        emit(F.gb_final[model] + t, (a4[0] + a4[1]) + (a4[2] + a4[3]));
+        return;
+    }
+    const bool dir = bx < 32;
+    // tile origin: dW_dir rows j0.. x columns m0.. | dW_final rows m0.. x columns k0..
+    const int row0 = dir ? 32 * (bx >> 3) : 32 * ((bx - 32) >> 3), col0 = dir ? 32 * (bx & 7) : 32 * ((bx - 32) & 7);
+    f32x16 acc;
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) {
-                const float b = sb[c][kk];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int m = lane & 31, kh = lane >> 5;              // MFMA operand lane: row / column m, inner index parity kh
+    if (dir) {
+        // out[j][c] = sum_k G[j0 + j][k] W_f[m0 + c][k]:  A[j][k] = G rows, B[k][c] = W_f rows; both staged row-major, pitch PA
+        float* sa = lds;
+        float* sb = lds + 32 * PA;
+        float4 va[8], vb[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sa[r0 + 8 * i][kk], b, acc[i]);
-            }
-        }
-        const float bm = bf[m0 + c];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = j0 + r0 + 8 * i;
-            emit(F.gw_dir[model] + (size_t)j * kParamIn[9] + m0 + c, __builtin_fmaf(sv[j], bm, acc[i]));
-        }
-    } else if (bx < 96) {
-        const int m0 = 32 * ((bx - 32) >> 3), k0 = 32 * ((bx - 32) & 7);
-        for (int j0 = 0; j0 < 128; j0 += 32) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sa[r0 + 8 * i][c] = Wdx[(size_t)(j0 + r0 + 8 * i) * 256 + m0 + c];
-                sb[r0 + 8 * i][c] = Gm[(size_t)(j0 + r0 + 8 * i) * 256 + k0 + c];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                const float b = sb[jj][c];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sa[jj][r0 + 8 * i], b, acc[i]);
-            }
+        for (int i = 0; i < 8; ++i) {                     // row (t >> 6) + 4 i, floats 4 (t & 63) ..
+            const int row = (t >> 6) + 4 * i;
+            va[i] = reinterpret_cast<const float4*>(Gm + (size_t)(row0 + row) * 256)[t & 63];
+            vb[i] = reinterpret_cast<const float4*>(Wf + (size_t)(col0 + row) * 256)[t & 63];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) emit(F.gw_final[model] + (size_t)(m0 + r0 + 8 * i) * 256 + k0 + c, acc[i]);
+        for (int i = 0; i < 8; ++i) {
+            const int o = ((t >> 6) + 4 * i) * PA + 4 * (t & 63);
+            sa[o] = va[i].x; sa[o + 1] = va[i].y; sa[o + 2] = va[i].z; sa[o + 3] = va[i].w;
+            sb[o] = vb[i].x; sb[o + 1] = vb[i].y; sb[o + 2] = vb[i].z; sb[o + 3] = vb[i].w;
+        }
+        __syncthreads();
+        const float* pa = sa + m * PA + 64 * wave + kh;   // this wave's quarter of k
+        const float* pb = sb + m * PA + 64 * wave + kh;
+#pragma unroll 8
+        for (int k = 0; k < 64; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
     } else {
-        float a = 0.f;
-        for (int j = 0; j < 128; ++j) a = __builtin_fmaf(Wdx[(size_t)j * 256 + t], sv[j], a);
-        emit(F.gb_final[model] + t, a);
+        // out[r][c] = sum_j W_dx[j][m0 + r] G[j][k0 + c]:  A[r][j] = W_dx columns, B[j][c] = G rows; staged [j][32], pitch PB
+        float* sa = lds;
+        float* sb = lds + 128 * PB;
+        const int c = t & 31, r0 = t >> 5;
+        float va[16], vb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                    // row r0 + 8 i (of 128), column c
+            va[i] = Wdx[(size_t)(r0 + 8 * i) * 256 + row0 + c];
+            vb[i] = Gm[(size_t)(r0 + 8 * i) * 256 + col0 + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sa[(r0 + 8 * i) * PB + c] = va[i];
+            sb[(r0 + 8 * i) * PB + c] = vb[i];
+        }
+        __syncthreads();
+        const float* pa = sa + (32 * wave + kh) * PB + m; // this wave's quarter of j
+        const float* pb = sb + (32 * wave + kh) * PB + m;
+#pragma unroll 8
+        for (int j = 0; j < 32; j += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j * PB], pb[j * PB], acc, 0, 0, 0);
+    }
+    // the four waves' partial tiles, summed in wave order; C/D layout: lane -> column lane & 31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave + 4 * i;
+        const float v = ((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane];
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = col0 + (lane & 31);
+        if (dir) emit(F.gw_dir[model] + (size_t)row * kParamIn[9] + col, __builtin_fmaf(sv[row], bf[col], v));
+        else emit(F.gw_final[model] + (size_t)row * 256 + col, v);
     }
 }
 

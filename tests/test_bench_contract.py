@@ -74,7 +74,7 @@ def test_driver_command_line_shape():
     assert lit["warmup"] == 5 and lit["steps"] == 20 and abs(lit["value"] - 1024 / (lit["ms_per_step"] * 1e-3)) <= 1e-3 * lit["value"]
     assert 0.8 * d["ms_per_step"] <= lit["ms_per_step"] <= 3.0 * d["ms_per_step"] and 0.05 <= lit["step_frac_mfma"] <= 0.6
     assert "cold_start_ms_per_step" not in d and "setup" not in d
-    assert d["launches_per_step"] == 6
+    assert d["launches_per_step"] == 7        # prologue, forward, chain, dW, reduce, fold, Adam
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and "mlp_bwd_dw_kernel" in roof["kernel"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 2e-3 and 0.15 <= roof["frac"] <= 0.45

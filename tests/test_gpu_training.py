@@ -721,3 +721,75 @@ def test_graphed_step_draws_a_fresh_batch_every_replay(dev):
     assert all(torch.isfinite(torch.tensor(losses)))
     with pytest.raises(ValueError):
         stepper({"rays": drawn[0], "rgbs": torch.zeros(64, 3, device=dev)})
+
+
+# ---- round 6: xyz_encoding_final folded out of the saved tensors (csrc/mlp_layout.h kDwJobs, mlp_bwd_fold_kernel) -------------------
+def _fold_case(dev, dtype, n=1000):
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(11)
+    p = O.make_params(5, 3.0, 0.1)
+    (m,), _ = build_models([p], dev, dtype)
+    rays = torch.cat([torch.rand(n, 3, generator=g) - 0.5, torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1),
+                      torch.full((n, 1), 2.0), torch.full((n, 1), 6.0)], 1).to(dev)
+    z = (2.0 + 4.0 * torch.rand(n, 1, generator=g)).to(dev)
+    acts = ops.alloc_acts(n, dtype, dev)
+    raw = ops.mlp_fwd_rays(rays, z, m.packed_weights(dtype), False, dtype, save=acts)
+    g_out = torch.randn(n, 4, generator=g).to(dev)
+    return ops, m, p, acts, raw, g_out
+
+
+def _poison_slots(buf, tile_bytes, first_piece, n_pieces, piece_bytes):
+    """0xFF (a NaN in bf16, fp32, e4m3 and e5m2 alike) over the `n_pieces` slab / pair slots from `first_piece` of every tile block"""
+    v = buf[:buf.numel() // tile_bytes * tile_bytes].view(-1, tile_bytes)
+    v[:, first_piece * piece_bytes:(first_piece + n_pieces) * piece_bytes] = 0xFF
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_f8"])
+def test_final_layer_fold_nobody_reads_f_or_its_gradient(dev, dtype):
+    """The forward does not save f = xyz_encoding_final(h8) and the chain does not store dL/df (nerf.py:70,116: a linear layer
+    without activation): their slots in the saved-activation and dY blocks are never written and never read.  Filled with NaNs —
+    before the backward in X, between the chain and the weight-gradient launch in dY — the 24 gradients come out bit-identical."""
+    ops, m, _, acts, raw, g_out = _fold_case(dev, dtype)
+    pb = m.packed_weights_bwd(dtype)
+    ws = {}
+    gw, gb, flat = ops.mlp_bwd(g_out, raw, pb, acts, dtype, workspace=ws)
+    ref = flat.clone()
+    assert torch.isfinite(ref).all() and ref.abs().max().item() > 0
+    # slot geometry (csrc/mlp_layout.h): bf16 / fp32 slabs kActFeat = 134 .. 149 of the 158 (+ 9 KiB of gates), kDyFeat = 10 .. 25 of 156;
+    # e4m3 / e5m2 pair pieces 67 .. 74 of 79 (+ 9 gate pieces + 1 scale piece), 5 .. 12 of 78 (+ 1 scale piece)
+    if dtype == "bf16_f8":
+        geo = ((79 + 9 + 1) * 1024, 67, 8, 1024), ((78 + 1) * 1024, 5, 8, 1024)
+    else:
+        sb = 2048 if dtype == "fp32" else 1024
+        geo = (158 * sb + 9 * 1024, 134, 16, sb), (156 * sb, 10, 16, sb)
+    _poison_slots(acts, *geo[0])
+    ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws)           # chain: writes dY (not dL/df)
+    _poison_slots(ws["dys"], *geo[1])
+    _, _, flat2 = ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=6, workspace=ws)   # dW + reduce + fold on the poisoned buffers
+    assert torch.equal(flat2, ref)
+
+
+def test_final_layer_fold_equals_the_direct_products_fp32(dev):
+    """dW_dir[:, :256] = sum_p dY_dir f^T, dW_final = sum_p (W_dx^T dY_dir) h8^T, db_final = sum_p W_dx^T dY_dir in float64 from the
+    oracle's own activations, against what the dir job's G and mlp_bwd_fold_kernel produce (fp32 path): the same sums,
+    re-associated — 1e-4 of each tensor's max |g| (the bound of the other fp32 gradients is 2e-4), measured value printed."""
+    ops, m, p, acts, raw, g_out = _fold_case(dev, "fp32", n=2000)
+    gw, gb, _ = ops.mlp_bwd(g_out, raw, m.packed_weights_bwd("fp32"), acts, "fp32")
+    # float64 autograd through the oracle's MLP on the same points
+    g = torch.Generator().manual_seed(11)
+    n = 2000
+    o = torch.rand(n, 3, generator=g) - 0.5
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    z = 2.0 + 4.0 * torch.rand(n, 1, generator=g)
+    x = torch.cat([O.posenc(o + d * z, 10), O.posenc(d, 4)], 1).double()
+    p64 = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    out = O.mlp_forward(p64, x)
+    (out * g_out.cpu().double()).sum().backward()
+    names = list(m.state_dict().keys())
+    for idx in (8, 9):                                     # xyz_encoding_final, dir_encoding
+        for kind, got in (("weight", gw[idx]), ("bias", gb[idx])):
+            name = [k for k in names if k.endswith(kind)][idx]
+            r = p64[name].grad
+            err = (got.cpu().double() - r).abs().max().item()
+            print("fold vs float64 autograd: %s max err / max |g| = %.2e" % (name, err / r.abs().max().item()))
+            assert err <= 1e-4 * r.abs().max().item() + 1e-9, (name, err, r.abs().max().item())
