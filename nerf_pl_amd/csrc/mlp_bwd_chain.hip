@@ -217,7 +217,7 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
 // and returns the scale byte of its own output.
 template <int PREC, int L, int NT, int NKS, bool MASK, bool F8, int IN_PAIRS, typename Slab>
 __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsigned lds_lo, const unsigned lds_hi, const unsigned sig_lds,
-                                                const Slab (&gin)[NKS == 17 ? 16 : NKS], Slab* out,
+                                                const Slab (&gin)[NKS - kBwdLayers[L].sigma_slab], Slab* out,
                                                 __amdgpu_buffer_rsrc_t acts, int gate_off, int mask_piece,
                                                 __amdgpu_buffer_rsrc_t dys, uint8_t* dy_tile, int dy_sec, int dy_scale_idx, int in_sec,
                                                 int in_sb, int lane) {
@@ -230,14 +230,15 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
     // (`lds_hi` is opaque to the optimiser: it would fold the constant back into one address per piece)
     typedef __attribute__((address_space(3))) const char* lds_cptr;
     auto piece_ptr = [&](int g) { return piece_off(g) < 65536 ? (lds_cptr)(lds_lo + (unsigned)piece_off(g)) : (lds_cptr)(lds_hi + (unsigned)(piece_off(g) - 65536)); };
-    // B operand of slab step ks: the layer's register slabs; the 17th slab of the final^T + sigma^T layer (the sigma head's
-    // gradient) is re-read from the wave's LDS stash for every tile instead of living in four more registers through the one
-    // layer that is already the register-pressure peak of the kernel (17 + 16 slabs live)
+    // B operand of slab step ks: the layer's register slabs; the last slab of the W_c^T + sigma^T layer (the sigma head's
+    // gradient) is re-read from the wave's LDS stash for every tile instead of living in four more registers
+    constexpr bool SIG = kBwdLayers[L].sigma_slab != 0;
+    constexpr int NIN = NKS - (SIG ? 1 : 0);
     auto bslab = [&](int ks) -> Slab {
-        if constexpr (NKS == 17) {
-            if (ks == 16) return *reinterpret_cast<__attribute__((address_space(3))) const Slab*>(sig_lds);
+        if constexpr (SIG) {
+            if (ks == NIN) return *reinterpret_cast<__attribute__((address_space(3))) const Slab*>(sig_lds);
         }
-        return gin[ks < (NKS == 17 ? 16 : NKS) ? ks : 0];
+        return gin[ks < NIN ? ks : 0];
     };
     u32x4 gates = {0u, 0u, 0u, 0u};
     if (MASK)
@@ -348,7 +349,7 @@ __device__ __forceinline__ int run_bwd_layer_tm(BwdStream<PREC>& st, const unsig
             mk_slab(out[2 * t + sl], v8);
         }
         }
-        if constexpr (!F8 && L != kBwdLayerDir) {       // (dL/d(final), the dir^T layer's output, is not stored: mlp_layout.h kDwJobs)
+        if constexpr (!F8) {
             // per-layer descriptor: the (possibly runtime, wave-uniform) section offset sits in its SALU-computed base, the
             // per-tile offsets are immediates (soffset stays 0: gfx950 store-data hazard, see store_slab)
             __amdgpu_buffer_rsrc_t dys_l = __builtin_amdgcn_make_buffer_rsrc(dy_tile + (size_t)dy_sec * 64 * sizeof(Slab) * act_il(PREC), 0,
@@ -484,30 +485,29 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
     Slab g_in0[1] = {g_rgb};
     int sb = run_bwd_layer_tm<PREC, 0, 4, 1, true, F8, 0>(st, lds_lo, lds_hi, sig_lds, g_in0, gd, acts, kGateOff, kMaskPieceT, dys, dy_tile, kDyDir,
                                                           f8_dy_section(kDyDir), -1, 127, lane);
-    // dir^T : g_feat = W_dir[:, :256]^T g_a_dir   (feat has no activation)  -> dY_feat in ga, registers only   (F8: stores its input dY_dir)
-    sb = run_bwd_layer_tm<PREC, 1, 8, 8, false, F8, 4>(st, lds_lo, lds_hi, sig_lds, gd, ga, acts, kGateOff, 0, dys, dy_tile, kDyFeat, f8_dy_section(kDyFeat),
-                                                       kDyDir, sb, lane);
-    // (the sigma head's slab is the 17th K slab of the next layer: parked in LDS, see run_bwd_layer_tm)
+    // (the sigma head's slab is the 9th K slab of the next layer: parked in LDS, see run_bwd_layer_tm)
     *reinterpret_cast<__attribute__((address_space(3))) Slab*>(sig_lds) = g_sig;
-    // final^T + sigma^T : g_h8 ; mask with h8  -> dY_8 in gb   (its input dY_feat is stored in no mode: mlp_layout.h kDwJobs)
-    sb = run_bwd_layer_tm<PREC, 2, 8, 17, true, F8, 0>(st, lds_lo, lds_hi, sig_lds, ga, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
-                                                       f8_dy_section(dy_h(8)), kDyFeat, sb, lane);
-    // ---- layers 3..8 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
+    // W_c^T + sigma^T : g_h8 = (W_dir[:, :256] W_final)^T g_a_dir + W_sigma^T g_sigma ; mask with h8  -> dY_8 in gb
+    // (xyz_encoding_final has no activation: folded, mlp_layout.h kLayers / kBwdLayers; F8: stores its input dY_dir)
+    static_assert(kBwdLayerFold == 1, "layer sequence below");
+    sb = run_bwd_layer_tm<PREC, 1, 8, 9, true, F8, 4>(st, lds_lo, lds_hi, sig_lds, gd, gb, acts, kGateOff, mask_piece_h(8), dys, dy_tile, dy_h(8),
+                                                      f8_dy_section(dy_h(8)), kDyDir, sb, lane);
+    // ---- layers 2..7 (L8^T .. L3^T): ONE copy of the code of three layers, run twice.  Fully unrolled, the chain is 67-80 KB of
     // straight-line code against a 64 KiB instruction cache (profiles/archive/r02_slowbox_diagnosis.txt: on some MI355X boxes a kernel
     // over that size runs 1.5x slower for its instruction fetches alone).  A 256 x 256 layer is 4 chunks of the W^T stream, so
     // three layers later the stream is at the same piece offset within a chunk AND in the same ring slot (12 chunks = 0 mod 3):
     // the second pass differs only in wave-uniform values — the stream pointer (+12 chunks), the gate piece (-3), the dY
     // sections (+48 slabs) and scale dwords (+3).  Three layers flip the ga / gb ping-pong, so each pass ends by copying its
     // result back (64 register moves per 384 MFMAs).
-    static_assert(bwd_layer_pieces(3, PREC) * 3 % (kChunkPieces * kSlots) == 0, "three looped layers = a whole number of ring turns");
+    static_assert(bwd_layer_pieces(2, PREC) * 3 % (kChunkPieces * kSlots) == 0, "three looped layers = a whole number of ring turns");
 #define NH_BWD(L, IN, OUT, D)                                                                                                \
     sb = run_bwd_layer_tm<PREC, L, 8, 16, true, F8, 8>(st, lds_lo, lds_hi, sig_lds, reinterpret_cast<const Slab(&)[16]>(IN), OUT, acts, kGateOff, \
-                                                       mask_piece_h(10 - L) - (D), dys, dy_tile, dy_h(10 - L) + 16 * (D),            \
-                                                       f8_dy_section(dy_h(10 - L)) + (D), dy_h(11 - L) + 16 * (D), sb, lane);
+                                                       mask_piece_h(9 - L) - (D), dys, dy_tile, dy_h(9 - L) + 16 * (D),              \
+                                                       f8_dy_section(dy_h(9 - L)) + (D), dy_h(10 - L) + 16 * (D), sb, lane);
     if constexpr (PREC != NERFHIP_BF16) {
         // exact-fp32 variant (the parity configuration, one wave per SIMD): fully unrolled — its code is far beyond the instruction
         // cache either way (186 vs 124 KB) and the loop costs it 27 spilled registers
-        NH_BWD(3, gb, ga, 0) NH_BWD(4, ga, gb, 0) NH_BWD(5, gb, ga, 0) NH_BWD(6, ga, gb, 0) NH_BWD(7, gb, ga, 0) NH_BWD(8, ga, gb, 0)
+        NH_BWD(2, gb, ga, 0) NH_BWD(3, ga, gb, 0) NH_BWD(4, gb, ga, 0) NH_BWD(5, ga, gb, 0) NH_BWD(6, gb, ga, 0) NH_BWD(7, ga, gb, 0)
     } else {
         const uint8_t* const gsrc0 = st.gsrc;
         int n_pass;
@@ -518,16 +518,16 @@ void mlp_bwd_chain_kernel(BwdChainArgs A, const float* __restrict__ g_scale) {
             st.pending = 0;
             st.pending_prev = 0;
             const int d = 3 * pass;                              // layers the pass is ahead of the code's constants
-            NH_BWD(3, gb, ga, d) NH_BWD(4, ga, gb, d) NH_BWD(5, gb, ga, d)
+            NH_BWD(2, gb, ga, d) NH_BWD(3, ga, gb, d) NH_BWD(4, gb, ga, d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) gb[i] = ga[i];
-            st.gsrc += (size_t)(3 * bwd_layer_pieces(3, PREC)) * kPieceBytes;
+            st.gsrc += (size_t)(3 * bwd_layer_pieces(2, PREC)) * kPieceBytes;
         }
         st.pending = 0;
         st.pending_prev = 0;
         st.gsrc = gsrc0;
     }
-    NH_BWD(9, gb, ga, 0)
+    NH_BWD(8, gb, ga, 0)
 #undef NH_BWD
     if constexpr (F8 && PREC == NERFHIP_BF16) {              // the last section (dY_1) has no consuming layer: flush it
 #pragma unroll

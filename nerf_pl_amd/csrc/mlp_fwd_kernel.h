@@ -267,18 +267,18 @@ NH_HD constexpr int frag_base(int L) {            // fragments before layer L (e
 // pending-epilogue kinds
 constexpr int PK_NONE = 0, PK_RELU = 1, PK_LINEAR = 2, PK_SIGMA = 3;
 // per-layer facts (execution-order index, kLayers)
-NH_HD constexpr bool layer_relu(int L) { return L <= 7 || L == 10; }
+NH_HD constexpr bool layer_relu(int L) { return L <= 7 || L == kDirLayer; }
 NH_HD constexpr int pend_kind(int PL) {
     return PL < 0 ? PK_NONE : (PL == kSigmaLayer ? PK_SIGMA : (layer_relu(PL) ? PK_RELU : PK_LINEAR));
 }
 // saved-activation section / gate piece of a layer's OUTPUT; section a layer stores in the fp8 mode (its chain INPUT)
-NH_HD constexpr int layer_out_sec(int L) { return L <= 7 ? act_h(L + 1) : (L == 9 ? kActFeat : (L == 10 ? kActT : -1)); }
-NH_HD constexpr int layer_gate_piece(int L) { return L <= 7 ? mask_piece_h(L + 1) : (L == 10 ? kMaskPieceT : -1); }
-NH_HD constexpr int layer_in_sec(int L) {       // (the dir layer's input f = xyz_encoding_final's output is not saved: mlp_layout.h kDwJobs)
-    return (L >= 1 && L <= 7) ? act_h(L) : (L == 9 ? act_h(8) : (L == 11 ? kActT : -1));
+NH_HD constexpr int layer_out_sec(int L) { return L <= 7 ? act_h(L + 1) : (L == kDirLayer ? kActT : -1); }
+NH_HD constexpr int layer_gate_piece(int L) { return L <= 7 ? mask_piece_h(L + 1) : (L == kDirLayer ? kMaskPieceT : -1); }
+NH_HD constexpr int layer_in_sec(int L) {       // (the dir layer runs on h8 through the folded final layer: mlp_layout.h kLayers)
+    return (L >= 1 && L <= 7) ? act_h(L) : (L == kDirLayer ? act_h(8) : (L == kDirLayer + 1 ? kActT : -1));
 }
-// sections the activation-saving forward writes (everything but f, which no weight-gradient job reads)
-NH_HD constexpr bool layer_out_saved(int L) { return layer_out_sec(L) >= 0 && layer_out_sec(L) != kActFeat; }
+// sections the activation-saving forward writes
+NH_HD constexpr bool layer_out_saved(int L) { return layer_out_sec(L) >= 0; }
 
 #ifndef NERFHIP_EXP_NOPS
 #define NERFHIP_EXP_NOPS 0
@@ -793,9 +793,9 @@ __device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned
             if (valid && h == 0) out[p] = cx.acc[0][0];          // (n,1)   nerf.py:112-114
             return;
         } else {
-            run_layer_pipe<PREC, NCH, SV, 9, 10, 1, 8>(cx, st, hb, ha, nul, &sigma_p);        // xyz_encoding_final (no activation) -> ha
-            run_layer_pipe<PREC, NCH, SV, 10, 11, 1, 9>(cx, st, ha, hb, ha, &sigma_p);        // dir_encoding -> hb[0..7]
-            run_layer_pipe<PREC, NCH, SV, 11, -1, 1, 10>(cx, st, hb, nul, hb, &sigma_p);      // rgb head, accumulator 1
+            static_assert(kDirLayer == 9 && kNumLayers == 11, "layer sequence below");
+            run_layer_pipe<PREC, NCH, SV, 9, 10, 1, 8>(cx, st, hb, ha, nul, &sigma_p);        // dir_encoding on [enc_d | h8] (final folded in) -> ha[0..7]
+            run_layer_pipe<PREC, NCH, SV, 10, -1, 1, 9>(cx, st, ha, nul, ha, &sigma_p);       // rgb head, accumulator 1
             // (SAVE: output index from a recomputed lane id, otherwise the prologue's 64-bit address stays live across the network)
             const int lane_o = SAVE ? fresh_lane_opaque() : lane;
             const int64_t po = (int64_t)blk * (32 * NW) + wave * 32 + (lane_o & 31);

@@ -57,9 +57,15 @@ struct Layer {
     int chain_slabs;  // slabs fed by the previous layer's registers
 };
 
-// kernel execution order
-constexpr int kNumLayers = 12;
+// kernel execution order.  xyz_encoding_final is NOT a layer of the kernels (round 6): it has no activation (nerf.py:70,116), so
+//     dir_encoding(cat([final(h8), dir])) = relu(W_c h8 + W_dd enc_d + b_c),   W_c = W_dir[:, :256] W_final,  b_c = W_dir[:, :256] b_final + b_dir
+// and the dir layer runs on h8 directly with the PRODUCT matrix, which the pack kernels form in fp32 (fold_wc / fold_bc in
+// mlp_pack_pieces.h: one 256-term fmaf chain per element, the same chain for the forward image and the W^T image, so both round to
+// the same bf16).  11 % fewer MFMAs per point in the forward, 18 % fewer in the backward chain; the parameter gradients of both
+// original layers follow from G = dL/dW_c (kDwJobs below).  The layer-by-layer path (linear.hip) keeps the reference's two layers.
+constexpr int kNumLayers = 11;
 constexpr int kSigmaLayer = 8;     // index (in this table) of the sigma head
+constexpr int kDirLayer = 9;       // ... of the dir layer (folded: weights W_c, bias b_c)
 constexpr Layer kLayers[kNumLayers] = {
     {0, 8, 256, IN_XYZ, 4, 0},         // xyz_encoding_1          nerf.py:62-63
     {1, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_2
@@ -70,8 +76,7 @@ constexpr Layer kLayers[kNumLayers] = {
     {6, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_7
     {7, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_8
     {10, 1, 1, IN_CHAIN, 0, 16},       // sigma (raw)                                   nerf.py:78,112
-    {8, 8, 256, IN_CHAIN, 0, 16},      // xyz_encoding_final (no activation)            nerf.py:70,116
-    {9, 4, 128, IN_DIR_CHAIN, 2, 16},  // dir_encoding: cat([final, input_dir])         nerf.py:73-75,118
+    {9, 4, 128, IN_DIR_CHAIN, 2, 16},  // dir_encoding o xyz_encoding_final on [input_dir | h8]   nerf.py:70,73-75,116-118
     {11, 1, 3, IN_CHAIN, 0, 8},        // rgb (sigmoid)                                 nerf.py:79-81
 };
 
@@ -146,7 +151,8 @@ NH_HD constexpr int xyz_slot_channel(int ks, int h, int j) { return enc_slot_cha
 NH_HD constexpr int dir_slot_channel(int ks, int h, int j) { return enc_slot_channel(4, kDirSlabs, ks, h, j); }
 NH_HD constexpr int chain_feature(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-// Column of the reference weight matrix W[out][in] multiplied by slot (ks,h,j) of layer L; -1 = pad.
+// Column of the reference weight matrix W[out][in] multiplied by slot (ks,h,j) of layer L; -1 = pad.  (Dir layer: columns 0..255 are
+// those of the product matrix W_c — h8 features — in the place of W_dir's, the final layer's outputs.)
 NH_HD constexpr int layer_in_col(int L, int ks, int h, int j) {
     const Layer& ly = kLayers[L];
     if (ks < ly.enc_slabs) {
@@ -228,12 +234,11 @@ struct BwdLayer {
     int col0;       // first column of W used as output feature 0 (63 for the skip layer)
     int sigma_slab; // 1: the last slab is the sigma-head slab (W_sigma row 0 at slot h=0,j=0)
 };
-constexpr int kNumBwdLayers = 10;
-constexpr int kBwdLayerDir = 1;            // index (in the table below) of dir^T, whose output dL/d(final) stays in registers
+constexpr int kNumBwdLayers = 9;
+constexpr int kBwdLayerFold = 1;           // index (in the table below) of the folded layer: its W^T fragments are those of W_c (kLayers above)
 constexpr BwdLayer kBwdLayers[kNumBwdLayers] = {
     {11, 4, 1, 0, 0},    // rgb^T      : g_a_rgb(3)   -> g_t(128)
-    {9, 8, 8, 0, 0},     // dir^T      : g_a_dir(128) -> g_feat(256)       (feat columns 0..255 of W_dir)
-    {8, 8, 17, 0, 1},    // final^T+sigma^T : [g_feat(256) | g_sigma(1)] -> g_h8(256)
+    {9, 8, 9, 0, 1},     // W_c^T+sigma^T : [g_a_dir(128) | g_sigma(1)] -> g_h8(256)   (W_c = W_dir[:, :256] W_final: dL/d(final) never exists)
     {7, 8, 16, 0, 0},    // L8^T : g_a8 -> g_h7
     {6, 8, 16, 0, 0},    // L7^T
     {5, 8, 16, 0, 0},    // L6^T
@@ -266,12 +271,12 @@ NH_HD constexpr int bwd_chunks(int prec) { return bwd_padded_pieces(prec) / kChu
 //
 // The linear layer folded out of the saved tensors (round 6).  xyz_encoding_final has NO activation (nerf.py:70,116):
 //     f = W_f h8 + b_f,   u = W_dx f + W_dd enc_d + b_d   (dir_encoding's pre-activation, W_dir = [W_dx | W_dd], nerf.py:118)
-// so with  G = sum_p dY_dir[p] h8[p]^T  (128 x 256)  and  s = sum_p dY_dir[p] = db_dir  (128):
+// so with  G = sum_p dY_dir[p] h8[p]^T  (128 x 256, = dL/dW_c)  and  s = sum_p dY_dir[p] = db_dir  (128):
 //     dW_dx = sum_p dY_dir f^T = G W_f^T + s b_f^T        dW_f = sum_p (W_dx^T dY_dir) h8^T = W_dx^T G        db_f = W_dx^T s
-// Neither f (16 slabs of X per tile) nor dL/df (16 slabs of dY) is needed by the weight-gradient launch: the forward does not
-// save f, the chain does not store dL/df (it still forms it in registers for g_h8), the dir job multiplies dY_dir by h8 instead of
-// f — the same job class — and mlp_bwd_fold_kernel finishes the three gradients from G, s and an fp32 snapshot of W_f, W_dx, b_f
-// (the fold block at the end of the packed W^T image).  10 % fewer saved bytes written and read per point, 11 % fewer dW FLOPs.
+// Neither f (16 slabs of X per tile) nor dL/df (16 slabs of dY) exists anywhere: the forward and the chain run the folded layer
+// (kLayers / kBwdLayers above), the dir job multiplies dY_dir by h8 — the job class it always had — and mlp_bwd_fold_kernel
+// finishes the three gradients from G, s and an fp32 snapshot of W_f, W_dx, b_f (the fold block at the end of the packed W^T
+// image).  10 % fewer saved bytes written and read per point, 11 % fewer dW FLOPs.
 // Job kDwJobFinal keeps its table entry (parameter mapping) but has no workgroups and nothing in the reduce kernel.
 struct DwJob {
     int param;

@@ -20,6 +20,95 @@ struct MultiPackTable {
     uint8_t* packed_bwd[kPackMaxModels];
 };
 
+// ---- the folded layer's weights (mlp_layout.h kLayers): W_c = W_dir[:, :256] W_final (128 x 256), b_c = W_dir[:, :256] b_final + b_dir ----
+// Formed by the pack kernels themselves, one WAVE per 32 x 32 tile of W_c on the fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain over
+// m = 0..255 per element; operands straight from global memory, all loads independent), and written from the tile into BOTH images —
+// the forward's A fragments and the chain's W^T fragments take their bf16 (or fp32) values from the same fp32 numbers.  A first
+// version computed every element as a dot product inside pack_*_piece: 256 dependent load round trips per piece, 80 us in the
+// training step's prologue launch.  The generic piece functions therefore SKIP these pieces (fwd_piece_folded / bwd_piece_folded).
+constexpr int kFoldTiles = 4 * 8;              // (dir-feature tile rt, h8-feature tile ct) = tile / 8, tile % 8
+NH_HD constexpr bool fwd_piece_folded(int g, int prec) {
+    using namespace mlp;
+    const int g0 = layer_start(kDirLayer, prec), nks = layer_slabs(kDirLayer);
+    if (g >= bias_block_start(prec) && g < bias_block_start(prec) + bias_block_pieces(prec)) return g - bias_block_start(prec) == kDirLayer;
+    if (g < g0 || g >= g0 + layer_pieces(kDirLayer, prec)) return false;
+    return ((g - g0) / ppf(prec)) % nks >= kLayers[kDirLayer].enc_slabs;
+}
+NH_HD constexpr bool bwd_piece_folded(int g, int prec) {
+    using namespace mlp;
+    const int g0 = bwd_layer_start(kBwdLayerFold, prec), nks = kBwdLayers[kBwdLayerFold].nks;
+    if (g < g0 || g >= g0 + bwd_layer_pieces(kBwdLayerFold, prec)) return false;
+    return ((g - g0) / ppf(prec)) % nks < nks - 1;             // (the last slab is the sigma head's row: generic)
+}
+// one wave: tile `tile` of W_c -> its pieces of `packed` (forward image, may be null) and `packed_bwd` (W^T image, may be null);
+// `stage`: 32 x 33 floats of LDS owned by this wave
+template <int PREC>
+__device__ __forceinline__ void pack_fold_tile(const ParamTable& P, uint8_t* __restrict__ packed, uint8_t* __restrict__ packed_bwd, int tile,
+                                               float* stage, int lane) {
+    using namespace mlp;
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    const int rt = tile >> 3, ct = tile & 7;
+    const int r = lane & 31, kh = lane >> 5;
+    const float* __restrict__ wd = P.w[9] + (size_t)(32 * rt + r) * kParamIn[9] + kh;      // A[row r][m + kh]
+    const float* __restrict__ wf = P.w[8] + (size_t)kh * kW + 32 * ct + r;                  // B[m + kh][col r]
+    const float* __restrict__ bfin = P.b[8] + kh;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    float bacc = 0.0f;
+#pragma unroll 16
+    for (int m = 0; m < kW; m += 2) {
+        const float a = wd[m];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[(size_t)m * kW], acc, 0, 0, 0);
+        bacc = __builtin_fmaf(a, bfin[m], bacc);
+    }
+    // C/D layout: lane -> column lane & 31, register q -> row (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) stage[((q & 3) + 8 * (q >> 2) + 4 * kh) * 33 + r] = acc[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (one wave: no s_barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    const int h = kh;
+    constexpr int PPF = ppf(PREC);
+    auto emit = [&](uint8_t* img, int g0, const float (&v)[8]) {
+        if (PREC == NERFHIP_BF16) {
+            typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+            bf16x8 pk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = (__bf16)v[j];
+            reinterpret_cast<uint4*>(img + (size_t)g0 * kPieceBytes)[lane] = *reinterpret_cast<uint4*>(&pk);
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+                reinterpret_cast<uint4*>(img + (size_t)(g0 + sub) * kPieceBytes)[lane] =
+                    make_uint4(__float_as_uint(v[4 * sub]), __float_as_uint(v[4 * sub + 1]), __float_as_uint(v[4 * sub + 2]), __float_as_uint(v[4 * sub + 3]));
+        }
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+        if (packed) {            // forward fragment (tile rt, slab enc + 2 ct + s2): lane (m, h) = row m, columns chain_feature(2 ct + s2, h, j)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = stage[r * 33 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)];
+            emit(packed, layer_start(kDirLayer, PREC) + (rt * layer_slabs(kDirLayer) + kLayers[kDirLayer].enc_slabs + 2 * ct + s2) * PPF, v);
+        }
+        if (packed_bwd) {        // W^T fragment (tile ct, slab 2 rt + s2): lane (m, h) = h8 feature m, dir features chain_feature(2 rt + s2, h, j)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = stage[(16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * 33 + r];
+            emit(packed_bwd, bwd_layer_start(kBwdLayerFold, PREC) + (ct * kBwdLayers[kBwdLayerFold].nks + 2 * rt + s2) * PPF, v);
+        }
+    }
+    if (packed && ct == 0) {     // b_c rows 32 rt ..: the two lane halves hold the even / odd m partial sums
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        stage[kh * 33 + r] = bacc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float* bias = reinterpret_cast<float*>(packed + (size_t)(bias_block_start(PREC) + kDirLayer) * kPieceBytes);
+        if (kh == 0) bias[32 * rt + r] = P.b[9][32 * rt + r] + (stage[r] + stage[33 + r]);
+        if (rt == 0) bias[128 + 2 * lane] = bias[128 + 2 * lane + 1] = 0.0f;             // (outputs 128..255 of the piece: padding)
+    }
+}
+
 template <int PREC>
 __device__ __forceinline__ uint4 pack_fwd_piece(const ParamTable& P, int g, int lane) {
     using namespace mlp;
@@ -56,7 +145,7 @@ __device__ __forceinline__ uint4 pack_fwd_piece(const ParamTable& P, int g, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = layer_in_col(L, ks, h, j);
-                v[j] = (row < ly.n_out && col >= 0) ? W[(size_t)row * ldw + col] : 0.0f;
+                v[j] = (row < ly.n_out && col >= 0) ? W[(size_t)row * ldw + col] : 0.0f;      // (folded pieces: never stored, see pack_fold_tile)
             }
             if (PREC == NERFHIP_BF16) {
                 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -101,7 +190,7 @@ __device__ __forceinline__ uint4 pack_bwd_piece(const ParamTable& P, int g, int 
                 if (h == 0 && j == 0) v[j] = P.w[10][icol];
             } else {
                 const int o = chain_feature(ks, h, j);
-                if (o < kParamOut[ly.param] && icol < kParamIn[ly.param])
+                if (o < kParamOut[ly.param] && icol < kParamIn[ly.param])       // (folded pieces: never stored, see pack_fold_tile)
                     v[j] = P.w[ly.param][(size_t)o * kParamIn[ly.param] + icol];
             }
         }

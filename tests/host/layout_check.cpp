@@ -69,7 +69,7 @@ int main() {
                       "layer_start %d prec %d", L, prec);
             frag += layer_pieces(L, prec);
         }
-        CHECK(frag == (prec ? 1184 : 2368), "fragment pieces %d", frag);
+        CHECK(frag == (prec ? 1056 : 2112), "fragment pieces %d", frag);     // (11 layers: xyz_encoding_final is folded into the dir layer)
         CHECK(total_pieces(prec) == frag + bias_block_pieces(prec), "total pieces");
         CHECK(bias_block_start(prec) == layer_start(kLoopSecond - 1, prec) + layer_pieces(kLoopSecond - 1, prec), "bias block position");
         CHECK(bias_block_pieces(prec) % kChunkPieces == 0 && bias_block_pieces(prec) >= kNumLayers, "bias block size");

@@ -50,9 +50,12 @@ def test_abi_basics(lib):
         n = lib.nerfhip_mlp_packed_bytes(code)
         assert n > 0 and n % 32768 == 0
     assert lib.nerfhip_mlp_packed_bytes(7) == 0
-    # 1,184 (fp32: 2,368) fragment pieces + the chunk-padded bias block between layers 4 and 5 (mlp_layout.h)
-    assert lib.nerfhip_mlp_packed_bytes(1) == lib.nerfhip_mlp_packed_bytes(2) == (1184 + 32) * 1024
-    assert lib.nerfhip_mlp_packed_bytes(0) == (2368 + 64) * 1024
+    # 1,056 (fp32: 2,112) fragment pieces of the 11 kernel layers (xyz_encoding_final is folded into the dir layer) + the
+    # chunk-padded bias block between layers 4 and 5 (mlp_layout.h)
+    assert lib.nerfhip_mlp_packed_bytes(1) == lib.nerfhip_mlp_packed_bytes(2) == (1056 + 32) * 1024
+    assert lib.nerfhip_mlp_packed_bytes(0) == (2112 + 64) * 1024
+    # W^T stream of the chain (9 layers, chunk-padded) + the 385-piece fp32 fold block
+    assert lib.nerfhip_mlp_packed_bwd_bytes(1) == (992 + 385) * 1024 and lib.nerfhip_mlp_packed_bwd_bytes(0) == (1952 + 385) * 1024
 
 
 def test_no_cpu_fallback():
