@@ -26,7 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from bench_inputs import (DTYPE_LABEL, PARITY, FLOP_PER_POINT_DW, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, FLOP_PER_RAY_EVAL,  # noqa: E402
+from bench_inputs import (DTYPE_LABEL, PARITY, FLOP_PER_POINT_DW, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, FLOP_PER_RAY_EVAL, FLOP_PER_POINT_FULL_EXECUTED,
+                          FLOP_PER_POINT_DX_EXECUTED, FLOP_PER_POINT_DW_EXECUTED,  # noqa: E402
                           PEAK_HBM_GBS, PEAK_TFLOPS, cpu_baseline, synth_params, synth_rays, synth_store, synth_store_ndc)
 
 PROTOCOL_VERSION = 3      # 1: rounds 1-3 (build calls counted as warm-up); 2: rounds 4-5 (build + settle replays outside W + K, value = sustained,
@@ -393,7 +394,10 @@ def main():
               "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
               "traffic": traffic_db.get("mlp_fwd_kernel|%s|%d" % (a.dtype, B * (S + N)), {}).get("hbm_bytes_per_launch"),
-              "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min_us, 2)}
+              "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min_us, 2),
+              # `frac` prices the reference's GEMMs (1,186,816 FLOP / point); the kernel executes 1,055,744 of them per point:
+              # xyz_encoding_final has no activation and is folded into the dir layer (csrc/mlp_layout.h kLayers)
+              "frac_executed": round(FLOP_PER_POINT_FULL_EXECUTED * B * (S + N) / avg_us / 1e6 / PEAK_TFLOPS[a.dtype], 4)}
         if a.dtype != "fp32":
             # informational: what this chip sustains at all under back-to-back bf16 MFMAs (it is power-limited: the shader
             # clock settles at 1.45-1.83 GHz), measured by tools/probes/probe_mfma_rate.hip -> profiles/archive/r02_probe_mfma_rate.txt
@@ -429,6 +433,9 @@ def main():
             # whole-step MFMA fraction: algorithmic FLOPs of the step (GEMMs only) over the step time
             step_flops = (FLOP_PER_POINT_FULL + FLOP_PER_POINT_DX + FLOP_PER_POINT_DW) * B * (2 * S + N)
             extra["step_frac_mfma"] = round(step_flops / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
+            # ... and with the FLOPs the kernels execute (the final layer folded in forward, chain and dW: 88.7 % of the algorithmic figure)
+            extra["step_frac_mfma_executed"] = round((FLOP_PER_POINT_FULL_EXECUTED + FLOP_PER_POINT_DX_EXECUTED + FLOP_PER_POINT_DW_EXECUTED)
+                                                     * B * (2 * S + N) / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4)
             g_ = state["graphed"]
             if g_ is not None and g_.graph is not None:
                 from nerf_pl_amd.system import graph_node_count

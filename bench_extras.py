@@ -13,7 +13,8 @@ import sys
 
 import torch
 
-from bench_inputs import (FLOP_PER_POINT_DW, FLOP_PER_POINT_DW_EXECUTED, UNSAVED_SLABS_PER_TILE, FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, PEAK_HBM_GBS, PEAK_TFLOPS, PEAK_TFLOPS_FP8, ROOT,
+from bench_inputs import (FLOP_PER_POINT_DW, FLOP_PER_POINT_DW_EXECUTED, FLOP_PER_POINT_DX_EXECUTED, FLOP_PER_POINT_FULL_EXECUTED, UNSAVED_SLABS_PER_TILE,
+                          FLOP_PER_POINT_DX, FLOP_PER_POINT_FULL, PEAK_HBM_GBS, PEAK_TFLOPS, PEAK_TFLOPS_FP8, ROOT,
                           TRAFFIC_JSON, synth_params, synth_rays)
 
 BENCH_PY = os.path.join(ROOT, "bench.py")
@@ -235,12 +236,14 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 10 * 528 * 4096
         if not one_fwd:
             entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
-                  FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point")
+                  FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point",
+                  flops_executed=FLOP_PER_POINT_FULL_EXECUTED * P)
         fwd_bytes += act_b + 56 * P         # + per point: 16 B raw written and read back twice by the compositing waves, 16 B d loss / d raw, z
         if not merged:
             entry("mlp_bwd_chain_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
-                  FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read")
+                  FLOP_PER_POINT_DX * P, dy_b + gate_b + 32 * P, "dY written once, ReLU gate words + g_out/out read",
+                  flops_executed=FLOP_PER_POINT_DX_EXECUTED * P)
         chain_b += dy_b + gate_b + 32 * P
         if not merged:
             entry("mlp_bwd_dw_kernel", tag, P,
@@ -264,7 +267,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
               P_all, lambda: ops.render_train_fwd(rays, tgt_, gs_, S, N, pk_c, pk_f, dtype, a_c, a_f, False, 1.0, pr_, None, None, 0.0, True, u_),
               FLOP_PER_POINT_FULL * P_all, fwd_bytes,
               "saved activations + gates of both models written once; per point 16 B rgb sigma out and back (L2), 16 B d loss / d raw, depths",
-              key_name="mlp_render_kernel<train>")
+              key_name="mlp_render_kernel<train>", flops_executed=FLOP_PER_POINT_FULL_EXECUTED * P_all)
     if merged:
         wsm = {}
         ops.mlp_bwd_multi(entries, dtype, workspace=wsm)            # (chains included: fills the dY slabs the dW launch reads)
@@ -272,7 +275,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         n_slabs = int(lib.nerfhip_mlp_dw_workspace_bytes_multi(n_arr, 2, code)) // (4 * (8 * 10 * 64 * 16 + 8 * 64))
         ws_b = n_slabs * 528 * 4096 // 10        # average used blocks per partial slab (528 of a model's 10 jobs with workgroups together)
         entry("mlp_bwd_chain_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=1, workspace=wsm),
-              FLOP_PER_POINT_DX * P_all, chain_b, "dY of both models written once, ReLU gate words + g_out/out read", key_name="mlp_bwd_chain_kernel<merged>")
+              FLOP_PER_POINT_DX * P_all, chain_b, "dY of both models written once, ReLU gate words + g_out/out read", key_name="mlp_bwd_chain_kernel<merged>",
+              flops_executed=FLOP_PER_POINT_DX_EXECUTED * P_all)
         entry("mlp_bwd_dw_kernel", "fine + coarse pass in ONE launch", P_all, lambda: ops.mlp_bwd_multi(entries, dtype, phases=2, workspace=wsm),
               FLOP_PER_POINT_DW * P_all, dw_b, "every saved activation and dY slab of both models read once", key_name="mlp_bwd_dw_kernel<merged>",
               flops_executed=FLOP_PER_POINT_DW_EXECUTED * P_all)
@@ -328,8 +332,8 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         if (key_name, P) in executed:
             fe = executed[(key_name, P)]
             out[-1].update({"flops_executed": fe, "frac_mfma_executed_in_step": round(fe / max(in_mix[k], 1e-3) / 1e6 / peak, 4),
-                            "flops_note": "`flops` = the reference's weight-gradient GEMMs (SURVEY 8d); the launch executes `flops_executed`: "
-                                          "the final layer's gradients come from the dir job's G by two small fp32 products"})
+                            "flops_note": "`flops` = the reference's GEMMs (SURVEY 8d); the launch executes `flops_executed`: xyz_encoding_final "
+                                          "(no activation) is folded into the dir layer — one 256 x 256 product per point fewer"})
     out.sort(key=lambda r: -r["avg_launch_us"])
     del keep, entries, todo
     return out, round(mix_us, 1)

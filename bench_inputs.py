@@ -18,6 +18,11 @@ FLOP_PER_POINT_DW = 1186816        # weight-gradient GEMM: 593,408 MAC (the refe
 # from G = dY_dir^T h8 (the dir job, same size as before) by two small fp32 products per step instead of a 256 x 256 x P GEMM
 # (csrc/mlp_layout.h kDwJobs).  Reported beside the algorithmic figure as `flops_executed` / `frac_mfma_executed_in_step`.
 FLOP_PER_POINT_DW_EXECUTED = FLOP_PER_POINT_DW - 2 * 256 * 256
+# The forward and the backward chain run the same fold (kernel layers: dir_encoding o xyz_encoding_final on h8 with the product matrix
+# W_c = W_dir[:, :256] W_final, formed by the pack kernels): 256 x 256 MACs per point fewer each.  `frac` figures stay on the
+# reference's FLOPs (what a step of the reference computes); the `*_executed` figures are what the MFMA pipe actually ran.
+FLOP_PER_POINT_FULL_EXECUTED = FLOP_PER_POINT_FULL - 2 * 256 * 256
+FLOP_PER_POINT_DX_EXECUTED = FLOP_PER_POINT_DX - 2 * 256 * 256
 UNSAVED_SLABS_PER_TILE = 16        # slab slots of a 32-point tile block that nobody writes or reads: f in X, dL/df in dY (same source)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks of the forward / dX chain

@@ -6,41 +6,30 @@
 
 namespace nerfhip {
 
-// grids: one 64-lane workgroup per piece, then kFoldTiles workgroups for the folded layer's W_c tiles (pack_fold_tile)
+// grids: pack_blocks() workgroups of 256 threads per model (mlp_pack_pieces.h pack_model_block: the W_c tiles, then four pieces each)
 template <int PREC>
-__device__ __forceinline__ void pack_block(const ParamTable& P, uint8_t* __restrict__ packed, uint8_t* __restrict__ packed_bwd, int g) {
-    __shared__ float stage[32 * 33];
-    const int nf = packed ? mlp::padded_pieces(PREC) : 0, nb = packed_bwd ? mlp::bwd_image_pieces(PREC) : 0;
-    const int lane = threadIdx.x;
-    if (g < nf) {
-        if (!fwd_piece_folded(g, PREC)) reinterpret_cast<uint4*>(packed + (size_t)g * mlp::kPieceBytes)[lane] = pack_fwd_piece<PREC>(P, g, lane);
-    } else if (g < nf + nb) {
-        if (!bwd_piece_folded(g - nf, PREC))
-            reinterpret_cast<uint4*>(packed_bwd + (size_t)(g - nf) * mlp::kPieceBytes)[lane] = pack_bwd_piece<PREC>(P, g - nf, lane);
-    } else {
-        pack_fold_tile<PREC>(P, packed, packed_bwd, g - nf - nb, stage, lane);
-    }
+__global__ __launch_bounds__(kPackThreads) void mlp_pack_kernel(ParamTable P, uint8_t* __restrict__ packed) {
+    __shared__ float lds[kPackLdsFloats];
+    pack_model_block<PREC>(P, packed, nullptr, blockIdx.x, lds);
 }
 template <int PREC>
-__global__ __launch_bounds__(64) void mlp_pack_kernel(ParamTable P, uint8_t* __restrict__ packed) {
-    pack_block<PREC>(P, packed, nullptr, blockIdx.x);
+__global__ __launch_bounds__(kPackThreads) void mlp_pack_bwd_kernel(ParamTable P, uint8_t* __restrict__ packed) {
+    __shared__ float lds[kPackLdsFloats];
+    pack_model_block<PREC>(P, nullptr, packed, blockIdx.x, lds);
 }
 template <int PREC>
-__global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(ParamTable P, uint8_t* __restrict__ packed) {
-    pack_block<PREC>(P, nullptr, packed, blockIdx.x);
-}
-// forward pieces first, then the W^T pieces
-template <int PREC>
-__global__ __launch_bounds__(64) void mlp_pack_train_kernel(ParamTable P, uint8_t* __restrict__ packed,
-                                                            uint8_t* __restrict__ packed_bwd) {
-    pack_block<PREC>(P, packed, packed_bwd, blockIdx.x);
+__global__ __launch_bounds__(kPackThreads) void mlp_pack_train_kernel(ParamTable P, uint8_t* __restrict__ packed,
+                                                                      uint8_t* __restrict__ packed_bwd) {
+    __shared__ float lds[kPackLdsFloats];
+    pack_model_block<PREC>(P, packed, packed_bwd, blockIdx.x, lds);
 }
 
 // the same for up to kPackMaxModels models in ONE launch (blockIdx.y = model): a training step's coarse and fine network
 template <int PREC>
-__global__ __launch_bounds__(64) void mlp_pack_train_multi_kernel(MultiPackTable T) {
+__global__ __launch_bounds__(kPackThreads) void mlp_pack_train_multi_kernel(MultiPackTable T) {
+    __shared__ float lds[kPackLdsFloats];
     const int m = blockIdx.y;
-    pack_block<PREC>(T.P[m], T.packed[m], T.packed_bwd[m], blockIdx.x);
+    pack_model_block<PREC>(T.P[m], T.packed[m], T.packed_bwd[m], blockIdx.x, lds);
 }
 
 static int pack_prec(int dtype) {       // NERFHIP_BF16_F8 shares the bf16 weight images: only the saved tensors differ
@@ -73,12 +62,12 @@ extern "C" int nerfhip_mlp_pack_weights(const float* const* weights_host, const 
         P.w[i] = weights_host[i];
         P.b[i] = biases_host[i];
     }
-    const int n = nerfhip::mlp::padded_pieces(dtype) + nerfhip::kFoldTiles;
+    const int n = nerfhip::pack_blocks(dtype, true, false);
     if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL(nerfhip::mlp_pack_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
+        hipLaunchKernelGGL(nerfhip::mlp_pack_kernel<NERFHIP_BF16>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed);
     else
-        hipLaunchKernelGGL(nerfhip::mlp_pack_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
+        hipLaunchKernelGGL(nerfhip::mlp_pack_kernel<NERFHIP_F32>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed);
     return nerfhip_launch_status();
 }
@@ -95,11 +84,11 @@ extern "C" int nerfhip_mlp_pack_weights_bwd(const float* const* weights_host, co
         P.w[i] = weights_host[i];
         P.b[i] = biases_host[i];
     }
-    const int n = nerfhip::mlp::bwd_image_pieces(dtype) + nerfhip::kFoldTiles;
+    const int n = nerfhip::pack_blocks(dtype, false, true);
     if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
+        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_BF16>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
     else
-        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
+        hipLaunchKernelGGL(nerfhip::mlp_pack_bwd_kernel<NERFHIP_F32>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P, (uint8_t*)packed_bwd);
     return nerfhip_launch_status();
 }
 
@@ -115,12 +104,12 @@ extern "C" int nerfhip_mlp_pack_weights_train(const float* const* weights_host, 
         P.w[i] = weights_host[i];
         P.b[i] = biases_host[i];
     }
-    const int n = nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype) + nerfhip::kFoldTiles;
+    const int n = nerfhip::pack_blocks(dtype, true, true);
     if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_BF16>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_BF16>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed, (uint8_t*)packed_bwd);
     else
-        hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_F32>, dim3(n), dim3(64), 0, (hipStream_t)stream, P,
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_kernel<NERFHIP_F32>, dim3(n), dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, P,
                            (uint8_t*)packed, (uint8_t*)packed_bwd);
     return nerfhip_launch_status();
 }
@@ -145,10 +134,10 @@ extern "C" int nerfhip_mlp_pack_weights_train_multi(const float* const* weights_
             T.P[m].b[i] = biases_host[12 * mm + i];
         }
     }
-    const dim3 grid((unsigned)(nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype) + nerfhip::kFoldTiles), (unsigned)n_models);
+    const dim3 grid((unsigned)nerfhip::pack_blocks(dtype, true, true), (unsigned)n_models);
     if (dtype == NERFHIP_BF16)
-        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_BF16>, grid, dim3(64), 0, (hipStream_t)stream, T);
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_BF16>, grid, dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, T);
     else
-        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_F32>, grid, dim3(64), 0, (hipStream_t)stream, T);
+        hipLaunchKernelGGL(nerfhip::mlp_pack_train_multi_kernel<NERFHIP_F32>, grid, dim3(nerfhip::kPackThreads), 0, (hipStream_t)stream, T);
     return nerfhip_launch_status();
 }

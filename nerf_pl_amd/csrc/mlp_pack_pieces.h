@@ -21,12 +21,19 @@ struct MultiPackTable {
 };
 
 // ---- the folded layer's weights (mlp_layout.h kLayers): W_c = W_dir[:, :256] W_final (128 x 256), b_c = W_dir[:, :256] b_final + b_dir ----
-// Formed by the pack kernels themselves, one WAVE per 32 x 32 tile of W_c on the fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain over
-// m = 0..255 per element; operands straight from global memory, all loads independent), and written from the tile into BOTH images —
-// the forward's A fragments and the chain's W^T fragments take their bf16 (or fp32) values from the same fp32 numbers.  A first
-// version computed every element as a dot product inside pack_*_piece: 256 dependent load round trips per piece, 80 us in the
-// training step's prologue launch.  The generic piece functions therefore SKIP these pieces (fwd_piece_folded / bwd_piece_folded).
+// Formed by the pack kernels themselves, one 4-wave WORKGROUP per 32 x 32 tile of W_c on the fp32 MFMA (v_mfma_f32_32x32x2_f32: fmaf
+// chains), and written from the tile into BOTH images — the forward's A fragments and the chain's W^T fragments take their bf16 (or
+// fp32) values from the same fp32 numbers.  Operands in ONE memory round trip, every load independent and coalesced: the A tile
+// W_dir[32 rt .., 0..255] row by row (256 B per instruction) into LDS, where the MFMA's A operand — lane (row r, inner index m + kh) —
+// is a conflict-free read; the B operand W_final[m + kh][32 ct + r] straight into registers in the order the chain consumes it; each
+// wave takes a quarter of the inner dimension, the partial tiles are summed in wave order.
+// (History: per-element dot products inside pack_*_piece — 256 dependent load round trips per piece, 80 us in the training step's
+// prologue launch; one wave per tile with per-step loads — 25-65 us per tile, the prologue at 22 us against 13.)
+// The generic piece functions SKIP these pieces (fwd_piece_folded / bwd_piece_folded).
 constexpr int kFoldTiles = 4 * 8;              // (dir-feature tile rt, h8-feature tile ct) = tile / 8, tile % 8
+constexpr int kFoldPitch = 257;                // LDS pitch (floats) of the staged A tile
+constexpr int kPackLdsFloats = 32 * kFoldPitch + 4 * 16 * 64 + 32 * 33 + 4 * 64;     // A tile | 4 partial C tiles | C tile | bias partials
+constexpr int kPackThreads = 256;              // every pack kernel: 4 waves per workgroup = one W_c tile or four 1 KiB pieces
 NH_HD constexpr bool fwd_piece_folded(int g, int prec) {
     using namespace mlp;
     const int g0 = layer_start(kDirLayer, prec), nks = layer_slabs(kDirLayer);
@@ -40,33 +47,56 @@ NH_HD constexpr bool bwd_piece_folded(int g, int prec) {
     if (g < g0 || g >= g0 + bwd_layer_pieces(kBwdLayerFold, prec)) return false;
     return ((g - g0) / ppf(prec)) % nks < nks - 1;             // (the last slab is the sigma head's row: generic)
 }
-// one wave: tile `tile` of W_c -> its pieces of `packed` (forward image, may be null) and `packed_bwd` (W^T image, may be null);
-// `stage`: 32 x 33 floats of LDS owned by this wave
+// one 256-thread workgroup: tile `tile` of W_c -> its pieces of `packed` (forward image, may be null) and `packed_bwd` (W^T image,
+// may be null); `lds`: kPackLdsFloats floats
 template <int PREC>
 __device__ __forceinline__ void pack_fold_tile(const ParamTable& P, uint8_t* __restrict__ packed, uint8_t* __restrict__ packed_bwd, int tile,
-                                               float* stage, int lane) {
+                                               float* lds) {
     using namespace mlp;
     typedef __attribute__((ext_vector_type(16))) float f32x16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rt = tile >> 3, ct = tile & 7;
     const int r = lane & 31, kh = lane >> 5;
-    const float* __restrict__ wd = P.w[9] + (size_t)(32 * rt + r) * kParamIn[9] + kh;      // A[row r][m + kh]
-    const float* __restrict__ wf = P.w[8] + (size_t)kh * kW + 32 * ct + r;                  // B[m + kh][col r]
-    const float* __restrict__ bfin = P.b[8] + kh;
+    float* sa = lds;                                       // [32][kFoldPitch]
+    float* part = sa + 32 * kFoldPitch;                    // [4][16][64]
+    float* sc = part + 4 * 16 * 64;                        // [32][33]
+    float* pb = sc + 32 * 33;                              // [4][64]
+    // A: this wave's 8 rows of the tile; B and b_final: this wave's quarter of the inner dimension, m = 64 wave + 2 j + kh
+    const float* __restrict__ wd = P.w[9] + (size_t)(32 * rt + 8 * wave) * kParamIn[9] + lane;
+    const float* __restrict__ wf = P.w[8] + (size_t)(64 * wave + kh) * kW + 32 * ct + r;
+    const float* __restrict__ bfin = P.b[8] + 64 * wave + kh;
+    float va[32], vb[32], vf[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) va[i] = wd[(size_t)(i >> 2) * kParamIn[9] + 64 * (i & 3)];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) vb[j] = wf[(size_t)(2 * j) * kW];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) vf[j] = bfin[2 * j];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sa[(8 * wave + (i >> 2)) * kFoldPitch + 64 * (i & 3) + lane] = va[i];
+    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
     float bacc = 0.0f;
-#pragma unroll 16
-    for (int m = 0; m < kW; m += 2) {
-        const float a = wd[m];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[(size_t)m * kW], acc, 0, 0, 0);
-        bacc = __builtin_fmaf(a, bfin[m], bacc);
-    }
-    // C/D layout: lane -> column lane & 31, register q -> row (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    const float* pa = sa + r * kFoldPitch + 64 * wave + kh;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) stage[((q & 3) + 8 * (q >> 2) + 4 * kh) * 33 + r] = acc[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (one wave: no s_barrier needed)
-    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < 32; ++j) {
+        const float a = pa[2 * j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb[j], acc, 0, 0, 0);
+        bacc = __builtin_fmaf(a, vf[j], bacc);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) part[(wave * 16 + q) * 64 + lane] = acc[q];
+    pb[wave * 64 + lane] = bacc;
+    __syncthreads();
+    // C/D layout: lane -> column lane & 31, register q -> row (q & 3) + 8 (q >> 2) + 4 (lane >> 5); partials summed in wave order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave + 4 * i;
+        sc[((q & 3) + 8 * (q >> 2) + 4 * kh) * 33 + r] = ((part[q * 64 + lane] + part[(16 + q) * 64 + lane]) + part[(32 + q) * 64 + lane]) + part[(48 + q) * 64 + lane];
+    }
+    __syncthreads();
     const int h = kh;
     constexpr int PPF = ppf(PREC);
     auto emit = [&](uint8_t* img, int g0, const float (&v)[8]) {
@@ -83,32 +113,36 @@ __device__ __forceinline__ void pack_fold_tile(const ParamTable& P, uint8_t* __r
                     make_uint4(__float_as_uint(v[4 * sub]), __float_as_uint(v[4 * sub + 1]), __float_as_uint(v[4 * sub + 2]), __float_as_uint(v[4 * sub + 3]));
         }
     };
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        float v[8];
+    // the tile's four fragments — forward (slab s2 = 0, 1), W^T (s2 = 0, 1) — one per wave
+    const int s2 = wave & 1;
+    float v[8];
+    if (wave < 2) {
         if (packed) {            // forward fragment (tile rt, slab enc + 2 ct + s2): lane (m, h) = row m, columns chain_feature(2 ct + s2, h, j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = stage[r * 33 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)];
+            for (int j = 0; j < 8; ++j) v[j] = sc[r * 33 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)];
             emit(packed, layer_start(kDirLayer, PREC) + (rt * layer_slabs(kDirLayer) + kLayers[kDirLayer].enc_slabs + 2 * ct + s2) * PPF, v);
         }
-        if (packed_bwd) {        // W^T fragment (tile ct, slab 2 rt + s2): lane (m, h) = h8 feature m, dir features chain_feature(2 rt + s2, h, j)
+    } else if (packed_bwd) {     // W^T fragment (tile ct, slab 2 rt + s2): lane (m, h) = h8 feature m, dir features chain_feature(2 rt + s2, h, j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = stage[(16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * 33 + r];
-            emit(packed_bwd, bwd_layer_start(kBwdLayerFold, PREC) + (ct * kBwdLayers[kBwdLayerFold].nks + 2 * rt + s2) * PPF, v);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = sc[(16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * 33 + r];
+        emit(packed_bwd, bwd_layer_start(kBwdLayerFold, PREC) + (ct * kBwdLayers[kBwdLayerFold].nks + 2 * rt + s2) * PPF, v);
     }
-    if (packed && ct == 0) {     // b_c rows 32 rt ..: the two lane halves hold the even / odd m partial sums
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        stage[kh * 33 + r] = bacc;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+    if (packed && ct == 0 && wave == 0) {     // b_c rows 32 rt ..: the lane halves hold the even / odd m partial sums of each wave's quarter
         float* bias = reinterpret_cast<float*>(packed + (size_t)(bias_block_start(PREC) + kDirLayer) * kPieceBytes);
-        if (kh == 0) bias[32 * rt + r] = P.b[9][32 * rt + r] + (stage[r] + stage[33 + r]);
+        if (kh == 0) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sum += pb[w * 64 + r] + pb[w * 64 + 32 + r];
+            bias[32 * rt + r] = P.b[9][32 * rt + r] + sum;
+        }
         if (rt == 0) bias[128 + 2 * lane] = bias[128 + 2 * lane + 1] = 0.0f;             // (outputs 128..255 of the piece: padding)
     }
 }
-
+// one 256-thread workgroup of a pack launch over ONE model: workgroups [0, kFoldTiles) = the W_c tiles (first: the longest units), then
+// four 1 KiB pieces per workgroup over the forward image (if `packed`) and the W^T image (if `packed_bwd`)
+NH_HD constexpr int pack_blocks(int prec, bool fwd, bool bwd) {
+    return kFoldTiles + ((fwd ? mlp::padded_pieces(prec) : 0) + (bwd ? mlp::bwd_image_pieces(prec) : 0) + 3) / 4;
+}
 template <int PREC>
 __device__ __forceinline__ uint4 pack_fwd_piece(const ParamTable& P, int g, int lane) {
     using namespace mlp;
@@ -206,6 +240,24 @@ __device__ __forceinline__ uint4 pack_bwd_piece(const ParamTable& P, int g, int 
         }
     }
     return outv;
+}
+
+template <int PREC>
+__device__ __forceinline__ void pack_model_block(const ParamTable& P, uint8_t* __restrict__ packed, uint8_t* __restrict__ packed_bwd, int b, float* lds) {
+    if (b < kFoldTiles) {
+        pack_fold_tile<PREC>(P, packed, packed_bwd, b, lds);
+        return;
+    }
+    const int nf = packed ? mlp::padded_pieces(PREC) : 0, nb = packed_bwd ? mlp::bwd_image_pieces(PREC) : 0;
+    const int lane = threadIdx.x & 63;
+    // the piece index is wave-uniform and SAID to be so (readfirstlane): the tables are then read with scalar loads
+    const int g = __builtin_amdgcn_readfirstlane((b - kFoldTiles) * 4 + (int)(threadIdx.x >> 6));
+    if (g < nf) {
+        if (!fwd_piece_folded(g, PREC)) reinterpret_cast<uint4*>(packed + (size_t)g * mlp::kPieceBytes)[lane] = pack_fwd_piece<PREC>(P, g, lane);
+    } else if (g < nf + nb) {
+        if (!bwd_piece_folded(g - nf, PREC))
+            reinterpret_cast<uint4*>(packed_bwd + (size_t)(g - nf) * mlp::kPieceBytes)[lane] = pack_bwd_piece<PREC>(P, g - nf, lane);
+    }
 }
 
 }  // namespace nerfhip

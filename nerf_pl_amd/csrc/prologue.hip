@@ -18,30 +18,17 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(DrawTable T, unsign
         philox_draws_block(T, seed_v, offset_v, state, (int)blockIdx.x, draw_blocks);
         return;
     }
-    const int nf = mlp::padded_pieces(PREC), nb = mlp::bwd_image_pieces(PREC);
-    __shared__ float stage[4][32 * 33];
-    const int lane = threadIdx.x & 63;
-    // one 1 KiB piece per wave, over (model, forward | W^T piece | W_c tile of the folded layer).  The piece index is wave-uniform and
-    // SAID to be so (readfirstlane): the model's tables are then read straight from the kernel arguments with scalar loads, as in
-    // mlp_pack_train_multi_kernel.
-    // (Round 4 first selected them into a local ParamTable; pack_*_piece index that table by layer, a dynamically indexed local
-    // lives in scratch memory — 200 B per lane, 59 MB of scratch stores per launch — and the launch took 29 us in the step's trace.)
-    const int wv = (int)(threadIdx.x >> 6);
-    const int piece = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - draw_blocks) * 4 + wv);
-    const int units = nf + nb + kFoldTiles;
-    const int m = piece / units, g = piece - m * units;
+    // the rest of the grid packs: pack_blocks() workgroups per model (mlp_pack_pieces.h pack_model_block: the W_c tiles of the folded
+    // layer first, then four 1 KiB pieces per workgroup).  The model index is uniform over the workgroup: its tables are read straight
+    // from the kernel arguments with scalar loads.  (Round 4 first selected them into a local ParamTable; pack_*_piece index that
+    // table by layer, a dynamically indexed local lives in scratch memory — 200 B per lane, 59 MB of scratch stores per launch — and
+    // the launch took 29 us in the step's trace.)
+    __shared__ float lds[kPackLdsFloats];
+    constexpr int per_model = pack_blocks(PREC, true, true);
+    const int bb = (int)blockIdx.x - draw_blocks;
+    const int m = bb / per_model, b = bb - m * per_model;
     if (m >= n_models) return;
-    // the W_c tiles FIRST in each model's range: they are the longest units of the launch (a 256-deep MFMA chain)
-    if (g < kFoldTiles) {
-        pack_fold_tile<PREC>(P.P[m], P.packed[m], P.packed_bwd[m], g, stage[wv], lane);
-    } else if (g - kFoldTiles < nf) {
-        const int gf = g - kFoldTiles;
-        if (!fwd_piece_folded(gf, PREC)) reinterpret_cast<uint4*>(P.packed[m] + (size_t)gf * mlp::kPieceBytes)[lane] = pack_fwd_piece<PREC>(P.P[m], gf, lane);
-    } else {
-        const int gb = g - kFoldTiles - nf;
-        if (!bwd_piece_folded(gb, PREC))
-            reinterpret_cast<uint4*>(P.packed_bwd[m] + (size_t)gb * mlp::kPieceBytes)[lane] = pack_bwd_piece<PREC>(P.P[m], gb, lane);
-    }
+    pack_model_block<PREC>(P.P[m], P.packed[m], P.packed_bwd[m], b, lds);
 }
 
 }  // namespace nerfhip
@@ -73,8 +60,7 @@ extern "C" int nerfhip_train_prologue(const nerfhip_draw* draws_host, int n_draw
             P.P[m].b[i] = biases_host[12 * mm + i];
         }
     }
-    const int pieces = n_models * (nerfhip::mlp::padded_pieces(dtype) + nerfhip::mlp::bwd_image_pieces(dtype) + nerfhip::kFoldTiles);
-    const dim3 grid((unsigned)(draw_blocks + (pieces + 3) / 4));
+    const dim3 grid((unsigned)(draw_blocks + n_models * nerfhip::pack_blocks(dtype, true, true)));
     if (dtype == NERFHIP_BF16)
         hipLaunchKernelGGL(nerfhip::train_prologue_kernel<NERFHIP_BF16>, grid, dim3(256), 0, (hipStream_t)stream, T, (unsigned long long)seed,
                            (unsigned long long)offset, reinterpret_cast<unsigned long long*>(state), draw_blocks, P, n_models);
