@@ -178,3 +178,45 @@ def test_fine_pass_conditioning(golden, golden_grads):
     moved = max(((g1[n] - g0[n]).abs().max() / g0[n].abs().max()).item() for n in g0)
     colour = max(((g1[n] - g0[n]).abs().max() / g0[n].abs().max()).item() for n in g0 if n.startswith(("rgb", "dir", "xyz_encoding_final")))
     assert 2e-4 <= moved <= 1e-2 and colour <= 2e-4, (moved, colour)           # measured 1.1e-3 / colour branch far below
+
+
+def test_reference_psnr_fixture_and_oracle_training_steps():
+    """tests/golden/reference_psnr_curves.json (minted by oracle/make_psnr_curves.py from the REAL reference's training loop,
+    train.py:103-117) on the CPU: structure (>= 24 live seeds, every checkpoint, every loss), the inits rebuilt here from the seed
+    give the recorded fp64 digest, and the ORACLE restatement trained on the same inits / batches / draws with torch.optim.Adam
+    reproduces the reference's first three training losses (before the trajectory turns chaotic) — which pins the oracle's
+    forward + loss + backward + Adam chain to the reference's, and the fixture's inputs to what tests/test_gpu_psnr_gate.py replays."""
+    import json
+    import os
+
+    from nerf_pl_amd.models import NeRF
+    from oracle.scenes import brick_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_psnr_curves.json")
+    with open(path) as fh:
+        doc = json.load(fh)
+    B, S, N, steps = doc["B"], doc["S"], doc["N"], doc["steps"]
+    live = [r for r in doc["runs"] if not r.get("dead") and r["psnr"][str(steps)] >= 16.0]
+    assert len(live) >= 24 and len({r["seed"] for r in doc["runs"]}) == len(doc["runs"])
+    for r in live:
+        assert len(r["loss"]) == steps and all(str(s) in r["psnr"] for s in range(50, steps + 1, 10))
+    rays, rgbs = brick_scene(doc["n_train_rays"], 1, "cpu")
+    for run in (live[0], live[-1]):
+        seed = run["seed"]
+        torch.manual_seed(seed)
+        init = [NeRF().state_dict(), NeRF().state_dict()]               # coarse then fine, default nn.Linear init (train.py:38-42)
+        s = sum(v.double().sum().item() for sd in init for v in sd.values())
+        q = sum((v.double() ** 2).sum().item() for sd in init for v in sd.values())
+        assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip((s, q), run["init_digest"]))
+        params = [{k: v.clone().requires_grad_(True) for k, v in sd.items()} for sd in init]
+        opt = torch.optim.Adam([v for p in params for v in p.values()], lr=5e-4, eps=1e-8)
+        perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1000 + seed))
+        for step in (1, 2, 3):
+            idx = perm[((step - 1) * B) % (rays.shape[0] - B):][:B]
+            rng = O.draw_rng(7000 * seed + step, B, S, N, 1.0)
+            res = O.render_rays(params, rays[idx], S, False, 1.0, 0.0, N, True, rng=rng)
+            loss = O.mse_loss(res, rgbs[idx])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            want = run["loss"][step - 1]
+            assert abs(loss.item() - want) <= 2e-5 * max(1.0, abs(want)), (seed, step, loss.item(), want)
