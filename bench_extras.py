@@ -32,6 +32,9 @@ def pmc_launch(a):
         m.mlp_dtype = a.dtype
         models.append(m.to(dev))
     rays = synth_rays(1234, B).to(dev)
+    from nerf_pl_amd.models.train_step import regen_enc_enabled
+    # (as the step does: bf16 leaves the input encodings out of the saved activations, the dW launch forms them again)
+    regen = regen_enc_enabled() and a.dtype == "bf16" and ops.render_supported(B, S, N, a.dtype) and S % 32 == 0 and (S + N) % 32 == 0
     with torch.no_grad():
         z = ops.sample_coarse_z(rays, S, False, 0.0)
         zf = ops.fine_z(z, torch.rand(B, S, device=dev), N)
@@ -43,7 +46,7 @@ def pmc_launch(a):
             pf, pb = pf.clone(), pb.clone()
             for _ in range(2):
                 raw = ops.mlp_fwd_rays(rays, zz, pf, False, a.dtype, save=acts)
-            entries.append((torch.randn_like(raw), raw, pb, acts))
+            entries.append((torch.randn_like(raw), raw, pb, acts) + ((rays, zz) if regen else ()))
         ws = {}
         for _ in range(2):
             ops.mlp_bwd_multi(entries, a.dtype, workspace=ws)           # chain x 2, merged dW, merged reduce
@@ -53,7 +56,7 @@ def pmc_launch(a):
             pk_c = models[0].packed_weights(a.dtype)
             for _ in range(2):
                 ops.render_train_fwd(rays, tgt, 2.0 / (3 * B), S, N, pk_c, pk, a.dtype, entries[1][3], entries[0][3], False, 1.0, pr, None, None,
-                                     0.0, True, u)
+                                     0.0, True, u, regen_enc=regen)
     torch.cuda.synchronize()
 
 
@@ -220,6 +223,9 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
 
     keep, entries, dw_b, P_all, chain_b = [], [], 0, 0, 0
     one_fwd = merged and ops.render_supported(B, S, N, dtype)       # the step's forward is ONE launch (nerfhip_render_train_fwd)
+    from nerf_pl_amd.models.train_step import regen_enc_enabled
+    # bf16 step: the 6 input-encoding slabs of a tile are not saved; the dW launch forms the 10 it would read from (rays, z)
+    regen = one_fwd and regen_enc_enabled() and dtype == "bf16" and S % 32 == 0 and (S + N) % 32 == 0
     fwd_bytes = 0
     for tag, model, zz in (("fine pass", models[1], zf), ("coarse pass", models[0], z)):
         P = zz.numel()
@@ -232,13 +238,14 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         ops.mlp_bwd(g_out, raw, pb, acts, dtype, workspace=ws)
         act_b, dy_b = acts.numel() - unsaved(P), ws["dys"].numel() - unsaved(P)        # bytes written / read, not allocated
         gate_b = (P + 31) // 32 * 9 * 1024
+        enc_w = (P + 31) // 32 * 6 * slab_b if regen else 0
         # split-K partials the reduce kernel reads: per split 528 used (out-tile, x-tile) blocks of 4 KiB over the 10 jobs with workgroups
         ws_b = int(lib.nerfhip_mlp_dw_splits(P, code)) // 10 * 528 * 4096
         if not one_fwd:
             entry("mlp_fwd_kernel<save>", tag, P, lambda zz=zz, pk=pk, acts=acts: ops.mlp_fwd_rays(rays, zz, pk, False, dtype, save=acts),
                   FLOP_PER_POINT_FULL * P, act_b + 20 * P, "saved activations + gates written once, 4 B z in + 16 B out per point",
                   flops_executed=FLOP_PER_POINT_FULL_EXECUTED * P)
-        fwd_bytes += act_b + 56 * P         # + per point: 16 B raw written and read back twice by the compositing waves, 16 B d loss / d raw, z
+        fwd_bytes += act_b - enc_w + 56 * P         # + per point: 16 B raw written and read back twice by the compositing waves, 16 B d loss / d raw, z
         if not merged:
             entry("mlp_bwd_chain_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=1, workspace=ws),
@@ -253,9 +260,9 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
             entry("mlp_bwd_reduce_kernel", tag, P,
                   lambda g_out=g_out, raw=raw, pb=pb, acts=acts, ws=ws: ops.mlp_bwd(g_out, raw, pb, acts, dtype, phases=4, workspace=ws),
                   0, ws_b + 2 * 595844 * 4, "split-K partial slabs read, 24 gradient tensors written")
-        entries.append((g_out, raw, pb, acts))
+        entries.append((g_out, raw, pb, acts) + ((rays, zz) if regen else ()))
         keep.append((acts, raw, g_out, ws))
-        dw_b += (act_b - gate_b) + dy_b
+        dw_b += (act_b - gate_b) + dy_b - enc_w      # (regen: the encoding slabs are neither saved nor read)
         P_all += P
     if one_fwd:
         tgt_ = torch.rand(B, 3, device=dev)
@@ -264,7 +271,7 @@ def kernel_table(models, rays, S, N, dtype, dev, traffic_db, merged):
         a_c, a_f = keep[1][0], keep[0][0]
         pk_c, pk_f = models[0].packed_weights(dtype), models[1].packed_weights(dtype)
         entry("mlp_render_kernel<train>", "the step's whole forward in ONE launch: coarse + fine MLP, compositing, loss gradient, fine depths, loss",
-              P_all, lambda: ops.render_train_fwd(rays, tgt_, gs_, S, N, pk_c, pk_f, dtype, a_c, a_f, False, 1.0, pr_, None, None, 0.0, True, u_),
+              P_all, lambda: ops.render_train_fwd(rays, tgt_, gs_, S, N, pk_c, pk_f, dtype, a_c, a_f, False, 1.0, pr_, None, None, 0.0, True, u_, regen_enc=regen),
               FLOP_PER_POINT_FULL * P_all, fwd_bytes,
               "saved activations + gates of both models written once; per point 16 B rgb sigma out and back (L2), 16 B d loss / d raw, depths",
               key_name="mlp_render_kernel<train>", flops_executed=FLOP_PER_POINT_FULL_EXECUTED * P_all)

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define NERFHIP_ABI_VERSION 2     /* 2: nerfhip_mlp_pack_weights_bwd takes the biases (fold block of the W^T image) */
+#define NERFHIP_ABI_VERSION 3     /* 2: nerfhip_mlp_pack_weights_bwd takes the biases (fold block of the W^T image); 3 (additive):
+                                   * nerfhip_render_args.regen_enc, nerfhip_mlp_bwd_multi_rays                                   */
 
 #define NERFHIP_E_BADARG (-1)  /* null pointer / non-positive size / unsupported shape */
 #define NERFHIP_E_UNSUPPORTED (-2)
@@ -262,6 +263,25 @@ int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_host, const fl
                           void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host, int accumulate, int dtype,
                           int phases, const float* g_scale, const nerfhip_adam_fused* adam, nerfhip_stream_t stream);
 
+/* nerfhip_mlp_bwd_multi for models evaluated ON RAYS (nerfhip_render_train_fwd with regen_enc = 1; NERFHIP_BF16): the
+ * weight-gradient launch does not read the positional encodings embedding_xyz(o + d z) / embedding_dir(d) (nerf.py:21-38,
+ * rendering.py:186,206-207) from the saved activations — they are the X operand of xyz_encoding_1, of the skip layer and of
+ * dir_encoding: 10 of the 282 KiB a 32-point tile is read for — but forms them again from 4 B of depth per point with the forward's
+ * own arithmetic (bit-identical operands, so bit-identical gradients).  enc (NULL = nerfhip_mlp_bwd_multi): per model the rays
+ * (B,8), the depths z (B,S) the forward evaluated the model at, and S; needs S % 32 == 0 and n = B S a multiple of 256.
+ * Measured on MI355X (round 6, same box, alternating): the forward gains 8-10 us of the 1024 x (64+128) step, this launch loses
+ * 12-25 — its ring iterations are paced by their instructions, not their bytes — so the Python step leaves it off by default. */
+typedef struct nerfhip_enc_source {
+    const float* rays[2];
+    const float* z[2];
+    int S[2];
+} nerfhip_enc_source;
+int nerfhip_mlp_bwd_multi_rays(int n_models, const float* const* g_out_host, const float* const* out_host, const int64_t* n_host,
+                               const void* const* packed_bwd_host, const void* const* acts_host, void* const* dys_host,
+                               void* dw_workspace, float* const* grad_w_host, float* const* grad_b_host, int accumulate, int dtype,
+                               int phases, const float* g_scale, const nerfhip_adam_fused* adam, const nerfhip_enc_source* enc,
+                               nerfhip_stream_t stream);
+
 /* d loss / d x of NeRF.forward on pre-embedded inputs (nerf.py:100-124 is differentiable w.r.t. x): from the dY slabs a
  * nerfhip_mlp_bwd call left in `dys`,  gx[:, 0:63] = W_1^T dY_1 + W_5[:, :63]^T dY_5,  gx[:, 63:90] = W_dir[:, 256:]^T dY_dir.
  * w_xyz1 / w_xyz5 / w_dir: the (out,in) fp32 weights of xyz_encoding_1, xyz_encoding_5, dir_encoding; gx (n, >= 90) with
@@ -428,6 +448,9 @@ typedef struct nerfhip_render_args {
     float* g_raw_fine;          /* (B,S_c+N_i,4)  out */
     float* out3;                /* [loss, psnr, mse] */
     uint32_t* ticket;           /* one zero-initialised device word owned by the caller; left at zero */
+    int regen_enc;              /* nerfhip_render_train_fwd, NERFHIP_BF16 only (ignored otherwise): 1 = the input-encoding slabs (6 of a
+                                 * tile block's 151 KiB) are NOT saved; the backward must then be nerfhip_mlp_bwd_multi_rays with
+                                 * these rays and z_coarse / z_fine, which forms them again                                     */
 } nerfhip_render_args;
 /* 1 when the single-launch kernels take this shape and arithmetic (dtype NERFHIP_F32 / NERFHIP_BF16 / NERFHIP_BF16_F8), else 0 */
 int nerfhip_render_supported(int64_t B, int S_c, int N_i, int dtype);

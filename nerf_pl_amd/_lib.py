@@ -93,6 +93,10 @@ SIGNATURES = {
     "nerfhip_mlp_bwd_multi": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
                               ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p, _c_void_p, _c_void_p],
+    "nerfhip_mlp_bwd_multi_rays": [_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_i64),
+                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_void_p,
+                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _int, _int, _int, _c_void_p, _c_void_p, _c_void_p,
+                                   _c_void_p],
     "nerfhip_linear_fwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _int, _int, _int, _int, _int, _c_void_p],
     "nerfhip_linear_bwd_input": [_c_void_p, _i64, _c_void_p, _i64, _int, _c_void_p, _i64, _c_void_p, _i64, _i64, _int, _int, _int,
                                  _int, _c_void_p],
@@ -128,7 +132,12 @@ class RenderArgs(ctypes.Structure):
                 ("u_stride", _i64), ("eps", _f32), ("row_total", _int), ("rgb_coarse", _c_void_p), ("depth_coarse", _c_void_p),
                 ("opacity_coarse", _c_void_p), ("rgb_fine", _c_void_p), ("depth_fine", _c_void_p), ("opacity_fine", _c_void_p),
                 ("target", _c_void_p), ("grad_scale", _f32), ("g_raw_coarse", _c_void_p), ("g_raw_fine", _c_void_p), ("out3", _c_void_p),
-                ("ticket", _c_void_p)]
+                ("ticket", _c_void_p), ("regen_enc", _int)]
+
+
+class EncSource(ctypes.Structure):
+    """include/nerfhip.h: nerfhip_enc_source"""
+    _fields_ = [("rays", _c_void_p * 2), ("z", _c_void_p * 2), ("S", _int * 2)]
 
 
 DRAW_UNIFORM, DRAW_NORMAL, DRAW_RANDINT = 0, 1, 2
@@ -160,7 +169,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
-    if lib.nerfhip_abi_version() != 2:
+    if lib.nerfhip_abi_version() != 3:
         raise NerfHipError("libnerfhip ABI version mismatch")
     _lib = lib
     return lib

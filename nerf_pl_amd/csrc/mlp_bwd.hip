@@ -120,6 +120,11 @@ struct DwJobTable {
     // fold_of[sigma job] = the dir job's index (its partial slabs hold the sigma partials in rows 4..7, which it does not use),
     // -1 everywhere else.
     int fold_of[kDwMaxJobs];
+    // Encodings regenerated instead of read (bf16, nerfhip_mlp_bwd_multi_rays): per MODEL the rays (B,8), the depths (B,S) its forward
+    // ran on and S / 32 (tiles per ray); enc_rays[m] == nullptr: the job's x1 section is read from the saved activations as before.
+    const float* enc_rays[kDwMaxModels];
+    const float* enc_z[kDwMaxModels];
+    int enc_tpr[kDwMaxModels];
 };
 static_assert(kDwJobs[kDwJobDir].x2_off == kDwJobs[kDwJobSigma].x1_off && kDwJobs[kDwJobDir].x2_slabs == 16 && kDwJobs[kDwJobDir].x1_slabs == 2 &&
               kDwJobs[kDwJobSigma].x1_slabs == 16 && kDwJobs[kDwJobSigma].dy_slabs == 2 && kDwJobs[kDwJobDir].dy_slabs == 8 &&
@@ -211,6 +216,54 @@ __device__ __forceinline__ void dw_bias_sum(const bf16x8& a, float& s0, float& s
 #endif
 }
 
+// 4 bytes per lane, global -> LDS (lane L lands at lds_dst + 4 L)
+__device__ __forceinline__ void glds4b_dw(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// Slab `ks` (wave-uniform) of the F-frequency encoding of v in the forward's slot order — the arithmetic of the bf16 forward's
+// encode_slots (mlp_fwd_kernel.h, NERFHIP_FAST_SINCOS path: x / 2 pi as a hi + lo pair, exact power-of-two scaling, v_fract, hardware
+// v_sin / v_cos in revolutions), operation for operation, so that the regenerated operand has the bits the forward multiplied by:
+// pair p = 4 ks + q is channel p % 3 at frequency 2^(2 (p / 3) + h); the slots behind the last pair hold the identity channels.
+template <int F, int SLABS>
+__device__ __forceinline__ bf16x8 dw_encode_slab(const float (&v)[3], int h, int ks) {
+    constexpr int NPAIR = 3 * (F / 2);
+    constexpr float kInv2PiHi = 0.15915494f, kInv2PiLo = 6.4206297e-9f;
+    float rh[3], rl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float vs = h ? 2.0f * v[c] : v[c];
+        rh[c] = vs * kInv2PiHi;
+        rl[c] = __builtin_fmaf(vs, kInv2PiHi, -rh[c]) + vs * kInv2PiLo;
+    }
+    bf16x8 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p = 4 * ks + q;
+        float s, co;
+        if (p < NPAIR) {
+            const int i = p / 3, c = p - 3 * i;
+            const float sc = (float)(1 << (2 * i));
+            const float rhc = c == 0 ? rh[0] : (c == 1 ? rh[1] : rh[2]), rlc = c == 0 ? rl[0] : (c == 1 ? rl[1] : rl[2]);
+            const float t = __builtin_amdgcn_fractf(rhc * sc) + rlc * sc;
+            s = __builtin_amdgcn_sinf(t);
+            co = __builtin_amdgcn_cosf(t);
+        } else {
+            const int tail = 2 * (p - NPAIR);
+            s = (tail == 0) ? (h ? v[2] : v[0]) : 0.0f;
+            co = (tail == 0) ? (h ? 0.0f : v[1]) : 0.0f;
+        }
+        out[2 * q] = (__bf16)s;
+        out[2 * q + 1] = (__bf16)co;
+    }
+    return out;
+}
+
 template <int PREC>
 __global__ __launch_bounds__(512, 2)
 void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
@@ -234,6 +287,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     const int64_t ntiles = jobs.ntiles[jid];
     const uint8_t* __restrict__ acts_base = jobs.acts[jid];
     const uint8_t* __restrict__ dys_base = jobs.dys[jid];
+    [[maybe_unused]] const float* __restrict__ enc_rays = jobs.enc_rays[jid / kNumDwJobs];      // non-null: regenerate the encodings
+    [[maybe_unused]] const float* __restrict__ enc_z = jobs.enc_z[jid / kNumDwJobs];
+    [[maybe_unused]] const int enc_tpr = jobs.enc_tpr[jid / kNumDwJobs];
     const int n_ot = jb.dy_slabs / 2;
     const int n_xs = jb.x1_slabs + jb.x2_slabs;
     const int n_xt = n_xs / 2;
@@ -289,8 +345,15 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     // LDS reads in flight under the current tile's MFMA (see mlp_bwd_dw_f8_kernel), LPW = ceil(pieces / 8) DMAs per wave per stage
     // (the surplus of the last round re-fetches the stage's last piece: every wave issues the SAME count, so one immediate
     // vmcnt serves all), D ring stages.
-    auto run = [&](auto nxt_c, auto nsl_c) {
+    auto run = [&](auto nxt_c, auto nsl_c, auto regen_c) {
         constexpr int NXT = decltype(nxt_c)::value, NSL = decltype(nsl_c)::value;
+        // REGEN (bf16; classes whose x1 section is an input encoding: first layer, skip layer, dir layer): the ENC encoding slabs of a
+        // stage are not fetched — waves 0 .. ENC - 1 form one slab each from the tile's depths (128 B, DMA'd one stage AHEAD of the
+        // stage's pieces into a small ring behind the stages) and the ray (scalar loads), and write it where the DMA would have put it
+        constexpr bool REGEN = decltype(regen_c)::value;
+        static_assert(!REGEN || (PREC == NERFHIP_BF16 && (NXT == 2 || NXT == 9 || NXT == 10)), "classes with an encoding section");
+        constexpr int ENC = REGEN ? (NXT == 9 ? kDirSlabs : kXyzSlabs) : 0;
+        constexpr int DYS = NXT == 9 ? 8 : 16;                     // (REGEN) dY slabs ahead of the encoding section in the stage image
         // class (9, 28) = the dir layer with the sigma head folded in: stage = [dY_dir 8][enc_dir 2][h8 16][dY_sigma 2] slabs; the
         // waves 4..7 (no dY tile of the dir layer is theirs) multiply dY_sigma by the h8 tiles 2 (w - 4), 2 (w - 4) + 1
         constexpr bool FOLD = NXT == 9 && NSL == kDwFoldStageSlabs;
@@ -298,10 +361,14 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         // workgroups — give wave (wi = wave >> 1, wj = wave & 1) the dY tiles 2 wi, 2 wi + 1 against the X tiles XW wj .. XW wj + XW - 1
         constexpr bool SPLIT2D = (PREC == NERFHIP_BF16) && NERFHIP_DW_SPLIT2D && (NXT == 8 || NXT == 10) && (NSL - 2 * NXT >= 16);
         constexpr int NP = NSL * SPP;                              // 1 KiB pieces per stage
-        constexpr int LPW = (NP + 7) / 8;
-        constexpr int D = dw_depth<PREC>(NP);
+        constexpr int NPD = NP - ENC;                              // ... of which are fetched
+        constexpr int LPWD = (NPD + 7) / 8;                        // piece DMAs per wave per stage
+        constexpr int LPW = LPWD + (REGEN ? 1 : 0);                // + the next stage's depths (every wave: one vmcnt immediate for all)
         constexpr int STAGE = (PREC == NERFHIP_BF16) ? NP * kPieceBytes : DwTraits<PREC>::STAGE_BYTES;
-        static_assert(D >= 2 && D * STAGE <= RING_BYTES, "ring stages of this job class");
+        constexpr int ZSLOT = 256;                                 // bytes of one stage's depths in LDS: 64 lanes x 4 B (lanes 32.. repeat)
+        constexpr int D0 = dw_depth<PREC>(NP);
+        constexpr int D = (REGEN && D0 * (STAGE + ZSLOT) > RING_BYTES) ? D0 - 1 : D0;
+        static_assert(D >= 2 && D * (STAGE + (REGEN ? ZSLOT : 0)) <= RING_BYTES, "ring stages of this job class");
         static_assert((D - 2) * LPW <= 63, "counted vmcnt");
 #if NERFHIP_DW_PROBE
         pr_depth = D;
@@ -311,27 +378,85 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         const uint8_t* abase = nullptr;
         const uint8_t* dbase = nullptr;
         unsigned slot = 0;
-        auto next_stage = [&](int64_t it) {
+        auto stage_tile = [&](int64_t it) {
             int64_t T = t_first + (it < my_tiles ? it : my_tiles - 1) * (NERFHIP_DW_BLOCKED ? 1 : nsplit);   // past the end: re-fetch
             if (T >= ntiles) T = ntiles - 1;
+            return T;
+        };
+        // (REGEN) depths of stage `st`: ring of D slots behind the stages, slot = st mod D
+        const float* zsrc = nullptr;
+        unsigned zslot = 0;
+        int z_issue = 0, g_slot = 0;
+        const unsigned lds_z = lds_base + (unsigned)(D * STAGE);
+        auto next_z = [&](int64_t st) {
+            zsrc = enc_z + stage_tile(st) * 32 + (lane & 31);
+            zslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_z + (unsigned)(z_issue * ZSLOT)));
+            z_issue = (z_issue + 1 == D) ? 0 : z_issue + 1;
+        };
+        auto next_stage = [&](int64_t it) {
+            const int64_t T = stage_tile(it);
             abase = acts_base + tile_block_off(T, act_tile_bytes(PREC), IL);      // (bf16: the block's pieces are IL KiB apart, mlp_layout.h)
             dbase = dys_base + tile_block_off(T, kDySlabs * 64 * (16 * SPP), IL);
             slot = lds_base + (unsigned)(s_issue * STAGE);
             s_issue = (s_issue + 1 == D) ? 0 : s_issue + 1;
+            if constexpr (REGEN) next_z(it + 1);
+        };
+        // (REGEN) the encoding slab `wave` of stage `st` (ring slot g_slot, depths in z slot g_slot) written into the stage image in the
+        // unit order the DMA gives the fetched slabs: (point n, half h) -> unit (2 n + h) ^ (8 x slab parity)
+        // The ray (origin, direction) of a stage's tile by SCALAR loads (constant address space, wave-uniform address), fetched one
+        // iteration before it is used: a vector load in the loop makes hipcc drain vmcnt — the whole DMA ring — every iteration
+        // (measured: the launch 400 -> 600 us), and a scalar load issued where it is needed puts a memory round trip into the
+        // iteration of every generating wave, hence — one barrier per stage — of the workgroup (430 us).
+        float ray_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto load_ray = [&](int64_t st) {
+            if (wave < ENC) {
+                const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)stage_tile(st) / (unsigned)enc_tpr));
+                typedef const float __attribute__((address_space(4))) * ConstF;
+                const ConstF rp = (ConstF)(uintptr_t)(enc_rays + (size_t)r * 8);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ray_next[c] = rp[c];
+            }
+        };
+        auto gen_stage = [&](int64_t st) {
+            if (wave < ENC) {
+                const int n = lane & 31, h = lane >> 5;
+                bf16x8 e;
+                if constexpr (NXT == 9) {
+                    const float dv[3] = {ray_next[3], ray_next[4], ray_next[5]};
+                    e = dw_encode_slab<4, kDirSlabs>(dv, h, wave);
+                } else {
+                    const float zv = *reinterpret_cast<const float*>(ring + D * STAGE + g_slot * ZSLOT + n * 4);
+                    float xv[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) xv[c] = nh_add(ray_next[c], nh_mul(ray_next[3 + c], zv));      // o + d z   rendering.py:206-207
+                    e = dw_encode_slab<10, kXyzSlabs>(xv, h, wave);
+                }
+                const int unit = (2 * n + h) ^ ((wave & 1) ? 8 : 0);
+                *reinterpret_cast<bf16x8*>(ring + g_slot * STAGE + (DYS + wave) * SLAB_BYTES + unit * 16) = e;
+            }
+            g_slot = (g_slot + 1 == D) ? 0 : g_slot + 1;
+            load_ray(st + 1);
         };
         // The last of a wave's LPW DMAs per stage: when the stage has REM = NP mod 8 pieces left for it (4 or 2 in the bf16 classes), the
         // 8 waves SHARE them — 8 / REM waves per piece, each fetching its 64 REM / 8 lanes' units under an EXEC mask — instead of
         // 8 - REM waves re-fetching the stage's last piece: every wave still issues the same count (one immediate vmcnt), and no byte
         // is fetched twice (round 4: the re-fetches were up to a quarter of a small job's DMAs, and nt loads do not stay in L2).
-        constexpr int REM = NP % 8;
+        constexpr int REM = NPD % 8;
         constexpr bool SHARE_LAST = (PREC == NERFHIP_BF16) && NERFHIP_DW_SHARE_LAST && (REM == 4 || REM == 2);
-        const int share_piece = NP - REM + (SHARE_LAST ? (wave * REM) / 8 : 0);
+        const int share_piece = NPD - REM + (SHARE_LAST ? (wave * REM) / 8 : 0);
         const unsigned long long share_mask = REM == 4 ? (0xffffffffull << (32 * (wave & 1))) : (0xffffull << (16 * (wave & 3)));
         auto issue_piece = [&](int i) {
+            if constexpr (REGEN) {
+                if (i == LPW - 1) {                                             // the NEXT stage's depths
+                    glds4b_dw(zsrc, zslot);
+                    return;
+                }
+            }
             int pi = wave + 8 * i;
-            const bool shared = SHARE_LAST && i == LPW - 1;
+            const bool shared = SHARE_LAST && i == LPWD - 1;
             if (shared) pi = share_piece;
-            if (pi >= NP) pi = NP - 1;                                          // (classes without sharing) duplicate DMA of the last piece
+            if (pi >= NPD) pi = NPD - 1;                                        // (classes without sharing) duplicate DMA of the last piece
+            if (REGEN && pi >= DYS) pi += ENC;                                  // fetched piece -> piece of the stage image
             const int sl = pi / SPP, sub = pi % SPP;
             const uint8_t* src;
             if (FOLD && sl >= kDwFoldSigmaSlab) src = dbase + (size_t)(kDySigma + sl - kDwFoldSigmaSlab) * 64 * (16 * SPP) * IL;
@@ -341,8 +466,10 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
             // fp32: a slab is 64 lanes x 32 B; piece `sub` = lanes' bytes [16*sub, 16*sub+16) is NOT contiguous,
             // so DMA whole 1 KiB lines instead: line q of the slab = lanes 32q..32q+31 (32 B each).
             const uint8_t* g = src + (size_t)sub * kPieceBytes + ((sl & 1) ? dma_off_odd : dma_off_even);
-            if (shared) glds16b_nt_masked(g, slot + (unsigned)(pi * kPieceBytes), share_mask);
-            else glds16b_nt(g, slot + (unsigned)(pi * kPieceBytes));
+            // (the destination is wave-uniform; said so, because hipcc otherwise shares a VGPR copy of pi x 1 KiB with the source address)
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot + (unsigned)(pi * kPieceBytes)));
+            if (shared) glds16b_nt_masked(g, dst, share_mask);
+            else glds16b_nt(g, dst);
         };
         auto issue_stage = [&](int64_t it) {
             next_stage(it);
@@ -355,8 +482,17 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
         // at all waiting for data.  One DMA every DMA_STEP MFMAs hides the path's back-pressure under the other wave's MFMAs.
         constexpr bool SPREAD = (PREC == NERFHIP_BF16) && NERFHIP_DW_SPREAD;
         constexpr int DMA_STEP = (2 * NXT) / LPW > 0 ? (2 * NXT) / LPW : 1;
+        if constexpr (REGEN) {                    // stage 0's depths lead the queue
+            next_z(0);
+            glds4b_dw(zsrc, zslot);
+            load_ray(0);
+        }
 #pragma unroll
         for (int s = 0; s < D - 1; ++s) issue_stage(s);
+        if constexpr (REGEN) {
+            wait_vm<(D - 1) * LPW>();             // (this wave's copy of) stage 0's depths landed; every wave fetched the same 128 B
+            gen_stage(0);
+        }
         for (int64_t it = 0; it < my_tiles; ++it) {
             // stage `it` landed (D-2 younger stages may still fly), everyone done with stage it-1
 #if NERFHIP_DW_PROBE
@@ -512,6 +648,9 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
                     }
                 }
             }
+            // (REGEN) the NEXT stage's encoding slabs, behind this stage's MFMAs: its depths came with stage `it`'s pieces (landed at
+            // this iteration's wait); the writes are visible to all behind the next barrier (whose wait includes lgkmcnt(0))
+            if constexpr (REGEN) gen_stage(it + 1);
 #if NERFHIP_DW_PROBE
             pr_comp += (shader_cycles() - t3) & 0xffffffffu;
 #endif
@@ -541,19 +680,38 @@ void mlp_bwd_dw_kernel(DwJobTable jobs, float* __restrict__ slabs) {
     };
     // job classes of mlp_layout.h kDwJobs: (X tiles, dY + X slabs per stage)
     using std::integral_constant;
+    using std::false_type;
+    using std::true_type;
+    bool regen = false;
+    if constexpr (PREC == NERFHIP_BF16) regen = enc_rays != nullptr;         // (host: only with the sigma head folded into the dir job)
     switch (n_xt) {
-        case 2: run(integral_constant<int, 2>{}, integral_constant<int, 20>{}); break;                 // first layer: 16 + 4
-        case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}); break;                 // rgb head: 2 + 8
+        case 2:                                                                                        // first layer: 16 + 4
+            if constexpr (PREC == NERFHIP_BF16) {
+                if (regen) { run(integral_constant<int, 2>{}, integral_constant<int, 20>{}, true_type{}); break; }
+            }
+            run(integral_constant<int, 2>{}, integral_constant<int, 20>{}, false_type{});
+            break;
+        case 4: run(integral_constant<int, 4>{}, integral_constant<int, 10>{}, false_type{}); break;   // rgb head: 2 + 8
         case 8:
-            if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{});     // 256 x 256 layers: 16 + 16
-            else run(integral_constant<int, 8>{}, integral_constant<int, 18>{});                       // sigma head on its own: 2 + 16
+            if (jb.dy_slabs == 16) run(integral_constant<int, 8>{}, integral_constant<int, 32>{}, false_type{});     // 256 x 256 layers: 16 + 16
+            else run(integral_constant<int, 8>{}, integral_constant<int, 18>{}, false_type{});         // sigma head on its own: 2 + 16
             break;
         case 9:
-            if (jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid)
-                run(integral_constant<int, 9>{}, integral_constant<int, kDwFoldStageSlabs>{});         // dir layer + folded sigma head: 8 + 18 + 2
-            else run(integral_constant<int, 9>{}, integral_constant<int, 26>{});                       // dir layer: 8 + 18
+            if (jobs.fold_of[(jid / kNumDwJobs) * kNumDwJobs + kDwJobSigma] == jid) {                  // dir layer + folded sigma head: 8 + 18 + 2
+                if constexpr (PREC == NERFHIP_BF16) {
+                    if (regen) { run(integral_constant<int, 9>{}, integral_constant<int, kDwFoldStageSlabs>{}, true_type{}); break; }
+                }
+                run(integral_constant<int, 9>{}, integral_constant<int, kDwFoldStageSlabs>{}, false_type{});
+            } else {
+                run(integral_constant<int, 9>{}, integral_constant<int, 26>{}, false_type{});          // dir layer: 8 + 18
+            }
             break;
-        default: run(integral_constant<int, 10>{}, integral_constant<int, 36>{}); break;               // skip layer: 16 + 20 (kDwMaxXTiles)
+        default:                                                                                       // skip layer: 16 + 20 (kDwMaxXTiles)
+            if constexpr (PREC == NERFHIP_BF16) {
+                if (regen) { run(integral_constant<int, 10>{}, integral_constant<int, 36>{}, true_type{}); break; }
+            }
+            run(integral_constant<int, 10>{}, integral_constant<int, 36>{}, false_type{});
+            break;
     }
 #if NERFHIP_DW_PROBE
     if (lane == 0 && blockIdx.x < 1024) {
@@ -1163,7 +1321,7 @@ static int dw_target_wgs(int dtype) {
 }
 // n_points[m] points of model m (m < n_models).  Fills jt (nsplit, soff, job, ntiles, njobs; the tensor pointers are the
 // caller's) when non-null; returns the number of workgroups = partial slabs.
-static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::DwJobTable* jt) {
+static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::DwJobTable* jt, const bool* regen = nullptr) {
     using namespace nerfhip;
     using namespace nerfhip::mlp;
     const int njobs = n_models * kNumDwJobs;
@@ -1182,7 +1340,13 @@ static int dw_plan(const int64_t* n_points, int n_models, int dtype, nerfhip::Dw
         const int ca = cost_a >= 0 ? cost_a : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_A : 1);
         const int cb = cost_b >= 0 ? cost_b : (dtype == NERFHIP_BF16 ? NERFHIP_DW_COST_B : 0);
         const bool fold = NERFHIP_DW_FOLD_SIGMA;             // (bf16 since round 4; e4m3 and fp32 since round 5; into the dir job since round 6)
-        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs + (fold && j % kNumDwJobs == kDwJobDir ? 2 : 0));
+        // (regen[m]: model m's encoding sections — x1 of the first, the skip and the dir layer — are formed in the kernel, not fetched.
+        // NERFHIP_DW_REGEN_PLAN=1 prices those jobs by the bytes they still fetch; by default the plan is the one of the saved
+        // encodings — the same workgroups, hence the same fp32 summation order and bit-identical gradients in both forms — and the
+        // three job classes simply finish early)
+        static const bool regen_plan = [] { const char* e = getenv("NERFHIP_DW_REGEN_PLAN"); return e && atoi(e) != 0; }();
+        const int enc_fetched = (regen_plan && regen && regen[j / kNumDwJobs] && jb.x1_enc != 0) ? jb.x1_slabs : 0;
+        cost[j] = ca + (int64_t)cb * (jb.dy_slabs + jb.x1_slabs + jb.x2_slabs - enc_fetched + (fold && j % kNumDwJobs == kDwJobDir ? 2 : 0));
         if (cost[j] < 1) cost[j] = 1;
         units[j] = tiles / (dtype == NERFHIP_BF16_F8 ? 2 : 1);
         cap[j] = NERFHIP_DW_MIN_ITERS > 0 ? units[j] / NERFHIP_DW_MIN_ITERS : units[j];
@@ -1277,8 +1441,29 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
                                      void* const* dys_host, void* dw_workspace, float* const* grad_w_host,
                                      float* const* grad_b_host, int accumulate, int dtype, int phases, const float* g_scale,
                                      const nerfhip_adam_fused* adam, nerfhip_stream_t stream) {
+    return nerfhip_mlp_bwd_multi_rays(n_models, g_out_host, out_host, n_host, packed_bwd_host, acts_host, dys_host, dw_workspace, grad_w_host,
+                                      grad_b_host, accumulate, dtype, phases, g_scale, adam, nullptr, stream);
+}
+
+extern "C" int nerfhip_mlp_bwd_multi_rays(int n_models, const float* const* g_out_host, const float* const* out_host,
+                                          const int64_t* n_host, const void* const* packed_bwd_host, const void* const* acts_host,
+                                          void* const* dys_host, void* dw_workspace, float* const* grad_w_host,
+                                          float* const* grad_b_host, int accumulate, int dtype, int phases, const float* g_scale,
+                                          const nerfhip_adam_fused* adam, const nerfhip_enc_source* enc, nerfhip_stream_t stream) {
     NERFHIP_CHECK_ARG(n_models >= 1 && n_models <= nerfhip::kDwMaxModels);
     if (!valid_dtype(dtype)) return NERFHIP_E_UNSUPPORTED;
+    bool regen[nerfhip::kDwMaxModels] = {false, false};
+    if (enc) {
+        // the encodings are formed in the bf16 weight-gradient kernel's dir + sigma job class only
+        if (dtype != NERFHIP_BF16 || !NERFHIP_DW_FOLD_SIGMA || !NERFHIP_DW_BLOCKED) return NERFHIP_E_UNSUPPORTED;
+        for (int m = 0; m < n_models; ++m) {
+            if (!enc->rays[m]) continue;                              // (this model's encodings were saved)
+            NERFHIP_CHECK_ARG(enc->z[m] && enc->S[m] > 0 && enc->S[m] % 32 == 0 && n_host[m] % 256 == 0 && n_host[m] % enc->S[m] == 0);
+            NERFHIP_CHECK_ARG(n_host[m] / 32 < (int64_t)1 << 31);
+            if ((((uintptr_t)enc->rays[m]) | ((uintptr_t)enc->z[m])) & 15) return NERFHIP_E_ALIGN;
+            regen[m] = true;
+        }
+    }
     NERFHIP_CHECK_ARG(g_out_host && out_host && n_host && packed_bwd_host && acts_host && dys_host && grad_w_host && grad_b_host);
     NERFHIP_CHECK_ARG(!(adam && accumulate));
     nerfhip::GradTable G;
@@ -1290,7 +1475,13 @@ extern "C" int nerfhip_mlp_bwd_multi(int n_models, const float* const* g_out_hos
              ((uintptr_t)dys_host[m])) & 15)
             return NERFHIP_E_ALIGN;
     }
-    const int nwg = dw_plan(n_host, n_models, dtype, &jt);
+    const int nwg = dw_plan(n_host, n_models, dtype, &jt, regen);
+    for (int m = 0; m < nerfhip::kDwMaxModels; ++m) {
+        const bool on = m < n_models && regen[m];
+        jt.enc_rays[m] = on ? enc->rays[m] : nullptr;
+        jt.enc_z[m] = on ? enc->z[m] : nullptr;
+        jt.enc_tpr[m] = on ? enc->S[m] / 32 : 1;
+    }
     float* const fold_scratch = (float*)dw_workspace + (size_t)nwg * nerfhip::mlp::kDwSlabFloats;
     nerfhip::FoldArgs F;
     for (int m = 0; m < nerfhip::kDwMaxModels; ++m) {

@@ -711,8 +711,11 @@ __device__ __forceinline__ void mlp_fwd_body(char* const lds_all, const unsigned
             save_scale_f8(st.pending, tile_base, f8_act_scale_off(), f8_x_section(kActEncD), 127, lane);
         }
     } else if (SAVE) {
-        save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
-        save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
+        // (wave-uniform) the bf16 step leaves the encoding slabs out: mlp_bwd_dw_kernel forms them again from (rays, z)
+        if (!(PREC == NERFHIP_BF16 && MODE == MODE_RAYS && zg.skip_enc_save)) {
+            save_slabs(st, tile_base, kActEncX, encx, kXyzSlabs, lane);
+            save_slabs(st, tile_base, kActEncD, encd, kDirSlabs, lane);
+        }
     }
     char* enc_x = stash_area + wave * kEncStash;      // wave-uniform stash bases
     char* enc_d = enc_x + kXyzSlabs * 64 * (int)sizeof(Slab);

@@ -33,6 +33,9 @@ struct FwdZGen {
     float* z_out;
     int use_disp;
     float perturb;
+    // activation-saving bf16 forward on rays: 1 = do NOT store the 6 input-encoding slabs of a tile block (mlp_layout.h kActEncX /
+    // kActEncD) — the weight-gradient launch regenerates them from the rays and the depths (nerfhip_mlp_bwd_multi_rays)
+    int skip_enc_save = 0;
 };
 
 namespace mlp {

@@ -130,7 +130,8 @@ void mlp_render_kernel(const RenderArgs args_by_value) {          // (read throu
         const bool fine = sp >= nc;
         const int S = fine ? a->S_c + a->N_i : a->S_c;
         const unsigned blk = fine ? blockIdx.x * (unsigned)nf + (unsigned)(sp - nc) : blockIdx.x * (unsigned)nc + (unsigned)sp;
-        const FwdZGen zg{fine ? nullptr : a->perturb_rand, fine ? nullptr : a->z_coarse, fine ? 0 : a->use_disp, fine ? 0.0f : a->perturb};
+        const FwdZGen zg{fine ? nullptr : a->perturb_rand, fine ? nullptr : a->z_coarse, fine ? 0 : a->use_disp, fine ? 0.0f : a->perturb,
+                          TRAIN ? a->regen_enc : 0};
         uint8_t* save = nullptr;
         if constexpr (TRAIN) save = (uint8_t*)(fine ? a->save_fine : a->save_coarse);
         if (TT && !fine)                  // (wave-uniform) the coarse network up to the density head: out = sigma (B, S_c)

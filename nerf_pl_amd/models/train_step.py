@@ -21,6 +21,8 @@ module runs that exact computation with the launches a fixed recipe allows:
 Every kernel forms its values with the same expressions as the modular path, so loss, outputs and d loss / d raw are
 bit-identical to it; the parameter gradients differ only in the fp32 summation order of the split-K partials.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -62,6 +64,24 @@ def _tracked(model):
     return ref is not None and ref() is not None
 
 
+_regen_enc = os.environ.get("NERFHIP_REGEN_ENC", "0") == "1"
+
+
+def regen_enc_enabled():
+    return _regen_enc
+
+
+def set_regen_enc(on):
+    """Process-wide: whether the bf16 fused step leaves the input encodings out of the saved activations and has the weight-gradient
+    launch form them again (nerfhip_render_args.regen_enc + nerfhip_mlp_bwd_multi_rays).  Bit-identical gradients; OFF by default
+    (NERFHIP_REGEN_ENC=1): measured on one box, alternating, the forward gains 8-10 us in the step and the dW launch — whose ring
+    iterations are paced by their instructions, not by their bytes — loses 12-25 (profiles/r06_regen_enc_abab.txt).  Returns the
+    previous setting."""
+    global _regen_enc
+    prev, _regen_enc = _regen_enc, bool(on)
+    return prev
+
+
 class _TrainRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, rays, rgbs, *params):
@@ -96,14 +116,18 @@ class _TrainRender(torch.autograd.Function):
             # the whole forward in ONE launch (nerfhip_render_train_fwd, csrc/mlp_render_kernel.h): workgroups that own 4 rays each run
             # coarse MLP -> compositing + loss gradient + compositing backward + fine depths -> fine MLP -> the same + loss values
             acts_f = ops.alloc_acts(B * (S + N), dtype, dev) if N > 0 else None
+            # bf16, opt-in (set_regen_enc): the positional encodings are not saved (6 of a tile's 151 KiB written, 10 of the 282 KiB
+            # the weight-gradient launch reads): that launch forms them again from the rays and the depths, bit for bit
+            regen = regen_enc_enabled() and ops.mlp_dtype_code(dtype) == ops.BF16 and S % 32 == 0 and (S + N) % 32 == 0
             o = ops.render_train_fwd(rays, rgbs, gscale, S, N, packs[0][0], packs[1][0] if N > 0 else None, dtype, acts_c, acts_f,
-                                     use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u)
+                                     use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std, white_back, u, regen_enc=regen)
             out3 = o["out3"]
             outs = [o["rgb_coarse"], o["depth_coarse"], o["opacity_coarse"]]
-            entries = [(o["g_raw_coarse"], o["raw_coarse"], packs[0][1], acts_c)]
+            entries = [(o["g_raw_coarse"], o["raw_coarse"], packs[0][1], acts_c) + ((rays, o["z_coarse"]) if regen else ())]
             if N > 0:
                 outs += [o["rgb_fine"], o["depth_fine"], o["opacity_fine"]]
-                entries.insert(0, (o["g_raw_fine"], o["raw_fine"], packs[1][1], acts_f))    # fine model first (as autograd would)
+                # fine model first (as autograd would)
+                entries.insert(0, (o["g_raw_fine"], o["raw_fine"], packs[1][1], acts_f) + ((rays, o["z_fine"]) if regen else ()))
         else:
             outs, entries, out3 = _forward_launches(models, rays, rgbs, S, N, dtype, use_disp, perturb, perturb_rand, noise_c, noise_f, noise_std,
                                                     white_back, u, gscale, packs, acts_c, dev)
@@ -142,8 +166,8 @@ class _TrainRender(torch.autograd.Function):
             # N > 1 ranks, form="per_model": per model chain -> dW -> reduce -> grad-ready hook, so that the fine model's all-reduce
             # travels while the coarse model's backward still runs (parallel.GradSync)
             grads = []
-            for m, (g_out, out, packed_bwd, acts) in zip(models, entries):
-                ((gw, gb, flat),) = ops.mlp_bwd_multi([(g_out, out, packed_bwd, acts)], dtype, g_scale=g_scale)
+            for m, entry in zip(models, entries):
+                ((gw, gb, flat),) = ops.mlp_bwd_multi([entry], dtype, g_scale=g_scale)
                 m._flat_grad = flat
                 m._grad_ready_hook(m, flat)
                 grads.append((gw, gb, flat))

@@ -638,9 +638,10 @@ def render_fwd(rays, n_samples, n_importance, packed_coarse, packed_fine, dtype,
 @device_guard
 def render_train_fwd(rays, target, grad_scale, n_samples, n_importance, packed_coarse, packed_fine, dtype, acts_coarse, acts_fine,
                      use_disp=False, perturb=0.0, perturb_rand=None, noise_coarse=None, noise_fine=None, noise_std=0.0,
-                     white_back=False, u=None, eps=1e-5):
+                     white_back=False, u=None, eps=1e-5, regen_enc=False):
     """The forward of a training step in ONE launch (nerfhip_render_train_fwd): render_fwd + saved activations + per pass the
-    loss gradient and the compositing backward (g_raw_*) + out3 = [loss, psnr, mse].  Returns the dict of written buffers."""
+    loss gradient and the compositing backward (g_raw_*) + out3 = [loss, psnr, mse].  Returns the dict of written buffers.
+    regen_enc (bf16): the input-encoding slabs are not saved; the backward must be mlp_bwd_multi with (rays, z, S) entries."""
     require_gpu(rays, target, perturb_rand, noise_coarse, noise_fine, u)
     rays, target = _c(rays), _c(target)
     B, S, N = rays.shape[0], int(n_samples), int(n_importance)
@@ -660,6 +661,7 @@ def render_train_fwd(rays, target, grad_scale, n_samples, n_importance, packed_c
     a.save_fine = acts_fine.data_ptr() if N > 0 else None
     a.target, a.grad_scale = target.data_ptr(), float(grad_scale)
     a.ticket = _ticket(dev).data_ptr()
+    a.regen_enc = int(bool(regen_enc) and mlp_dtype_code(dtype) == BF16)
     check(_lib.load().nerfhip_render_train_fwd(ctypes.addressof(a), mlp_dtype_code(dtype), stream_ptr()), "nerfhip_render_train_fwd")
     return bufs
 
@@ -793,15 +795,28 @@ def flat_grad_views(n_points, device, shapes=PARAM_SHAPES, out=None):
 
 def mlp_bwd_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=None):
     """Backward of several models with ONE dW launch and ONE reduce launch (nerfhip_mlp_bwd_multi).
-    entries: [(g_out (n,4), out (n,4), packed_bwd, acts)], n > 0.  adam: an _lib.AdamFused (the update then happens inside the
-    reduce kernel).  g_scale: device scalar multiplying every g_out inside the chain kernels (the upstream gradient of the loss).
+    entries: [(g_out (n,4), out (n,4), packed_bwd, acts)] or [(g_out, out, packed_bwd, acts, rays (B,8), z (B,S))] — the latter for
+    a bf16 model whose forward did not save its input encodings (render_train_fwd(regen_enc=True)): the weight-gradient launch forms
+    them again from the rays and the depths (nerfhip_mlp_bwd_multi_rays); n > 0.  adam: an _lib.AdamFused (the update then happens
+    inside the reduce kernel).  g_scale: device scalar multiplying every g_out inside the chain kernels (the upstream gradient of the loss).
     Returns [(gw list, gb list, flat)] per model."""
     code = mlp_dtype_code(dtype)
     lib = _lib.load()
     M = len(entries)
     dev = entries[0][1].device
     gs, outs, ns, dys, grads = [], [], [], [], []
-    for g_out, out, packed_bwd, acts in entries:
+    enc, keep_enc = None, []
+    for m, e in enumerate(entries):
+        g_out, out = e[0], e[1]
+        if len(e) > 4 and e[4] is not None:
+            if enc is None:
+                enc = _lib.EncSource()
+            rays_e, z_e = _c(e[4]), _c(e[5])
+            require_gpu(rays_e, z_e)
+            if rays_e.dtype != torch.float32 or z_e.dtype != torch.float32 or z_e.dim() != 2 or rays_e.shape[0] != z_e.shape[0]:
+                raise ValueError("mlp_bwd_multi: (rays (B,8), z (B,S)) fp32 expected")
+            enc.rays[m], enc.z[m], enc.S[m] = rays_e.data_ptr(), z_e.data_ptr(), int(z_e.shape[1])
+            keep_enc.append((rays_e, z_e))
         require_gpu(g_out, out)
         g_out = _c(g_out.float()).reshape(-1, 4)
         out = _c(out).reshape(-1, 4)
@@ -836,8 +851,9 @@ def mlp_bwd_multi(entries, dtype, adam=None, phases=7, workspace=None, g_scale=N
                 adam.grad_flat[m] = grads[m][2].data_ptr()
         if g_scale is not None:
             require_gpu(g_scale)
-        check(lib.nerfhip_mlp_bwd_multi(M, G, O, n_arr, PB, AC, DY, ptr(ws), GW, GB, 0, code, int(phases), ptr(g_scale),
-                                        ctypes.addressof(adam) if adam is not None else None, stream_ptr()), "nerfhip_mlp_bwd_multi")
+        check(lib.nerfhip_mlp_bwd_multi_rays(M, G, O, n_arr, PB, AC, DY, ptr(ws), GW, GB, 0, code, int(phases), ptr(g_scale),
+                                             ctypes.addressof(adam) if adam is not None else None,
+                                             ctypes.addressof(enc) if enc is not None else None, stream_ptr()), "nerfhip_mlp_bwd_multi_rays")
     return grads
 
 

@@ -42,7 +42,7 @@ def test_library_exports_every_header_symbol(lib):
 
 
 def test_abi_basics(lib):
-    assert lib.nerfhip_abi_version() == 2
+    assert lib.nerfhip_abi_version() == 3
     assert lib.nerfhip_error_string(0) == b"success"
     assert b"aligned" in lib.nerfhip_error_string(-3)
     # packed stream sizes: multiples of the 32 KiB ring chunk (mlp_layout.h)

@@ -211,3 +211,47 @@ def test_merged_dw_plan_shares_workgroups_in_proportion_to_points(dev):
     merged = lib.nerfhip_mlp_dw_workspace_bytes_multi(n, 2, 2) // slab
     single = lib.nerfhip_mlp_dw_workspace_bytes(1024 * 192, 2) // slab, lib.nerfhip_mlp_dw_workspace_bytes(1024 * 64, 2) // slab
     assert single[0] == 256 and 240 <= merged <= 256 and merged < single[0] + single[1], (merged, single)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(N_importance=0), dict(noise_std=1.0, white_back=False, perturb=0.0), dict(N_importance=128, rays=1024)])
+def test_bf16_step_without_saved_encodings_equals_the_step_with_them(dev, cfg, monkeypatch):
+    """The bf16 fused step does not save the positional encodings (nerfhip_render_args.regen_enc; the dW launch forms them again,
+    nerfhip_mlp_bwd_multi_rays).  Against the same step with the encodings saved and read: loss and PSNR bit-identical, every
+    gradient tensor equal up to the fp32 summation order of the split partials (the split plan weighs the jobs by the bytes they
+    fetch, which differ) — with the saved-activation buffers pre-filled with NaN bit patterns, so that a read of a slot the forward
+    no longer writes would surface as a NaN gradient."""
+    from nerf_pl_amd import ops
+    from nerf_pl_amd.models import train_step
+    real_alloc = ops.alloc_acts
+
+    def poisoned(*a, **k):
+        t = real_alloc(*a, **k)
+        t.fill_(0xFF)
+        return t
+    monkeypatch.setattr(ops, "alloc_acts", poisoned)
+    cfg = dict(cfg)
+    batch = _batch(dev, cfg.pop("rays", 300))
+    got = {}
+    for regen in (False, True):
+        prev = train_step.set_regen_enc(regen)
+        try:
+            system, opt = _system(dev, "bf16", **cfg)
+            system.fused_train_step = True
+            torch.manual_seed(11)
+            out = system.training_step(batch, 0)
+            opt.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+        finally:
+            train_step.set_regen_enc(prev)
+        got[regen] = (out["loss"].detach().clone(), out["log"]["train/psnr"].detach().clone(),
+                      {n: p.grad.detach().clone() for n, p in system.named_parameters()})
+    assert torch.equal(got[False][0], got[True][0]) and torch.equal(got[False][1], got[True][1])
+    worst = 0.0
+    for n, g in got[False][2].items():
+        h = got[True][2][n]
+        assert torch.isfinite(h).all() and torch.isfinite(g).all(), n
+        rel = (g - h).norm().item() / (g.norm().item() + 1e-20)
+        worst = max(worst, rel)
+        assert rel <= 2e-6, (cfg, n, rel)
+    print("bf16 step, encodings regenerated vs saved %s: worst relative L2 difference of a gradient tensor %.2e" % (cfg, worst))

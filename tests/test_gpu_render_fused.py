@@ -153,12 +153,16 @@ def test_render_rays_takes_the_single_launch_and_returns_the_same(dev, dtype, te
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_f8"])
 @pytest.mark.parametrize("B,S,N,noise_std,white_back,perturb", [(1024, 64, 128, 0.0, True, 1.0), (32, 64, 64, 1.0, False, 0.0), (16, 64, 0, 1.0, True, 1.0)])
-def test_training_forward_in_one_launch_is_the_four_launches(dev, dtype, B, S, N, noise_std, white_back, perturb):
+def test_training_forward_in_one_launch_is_the_four_launches(dev, dtype, B, S, N, noise_std, white_back, perturb, monkeypatch):
     """models/train_step.render_rays_train with the forward as ONE launch (nerfhip_render_train_fwd) and as the four launches of
     round 4: loss, PSNR, every rendered output and EVERY parameter gradient bit for bit (same saved activations, same d loss / d
-    raw -> the backward cannot tell the difference)."""
+    raw -> the backward cannot tell the difference).  (With the encodings saved in both: the bf16 one-launch step otherwise leaves them
+    to the weight-gradient launch, whose split plan then weighs the jobs differently — another fp32 summation order; that form has
+    its own tests, test_gpu_fused_step.py::test_bf16_step_without_saved_encodings_equals_the_step_with_them.)"""
     from nerf_pl_amd import ops
+    from nerf_pl_amd.models import train_step
     from nerf_pl_amd.models.train_step import render_rays_train
+    monkeypatch.setattr(train_step, "_regen_enc", False)
     rays = O.make_rays(4, B, "blender").to(dev)
     tgt = torch.rand(B, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     d = _draws(B, S, N, dev, seed=5)

@@ -793,3 +793,30 @@ def test_final_layer_fold_equals_the_direct_products_fp32(dev):
             err = (got.cpu().double() - r).abs().max().item()
             print("fold vs float64 autograd: %s max err / max |g| = %.2e" % (name, err / r.abs().max().item()))
             assert err <= 1e-4 * r.abs().max().item() + 1e-9, (name, err, r.abs().max().item())
+
+
+@pytest.mark.parametrize("B,S", [(32, 64), (8, 192), (64, 32)])
+def test_dw_regenerated_encodings_are_the_saved_ones_bf16(dev, B, S):
+    """nerfhip_mlp_bwd_multi_rays (bf16): the weight-gradient launch forms embedding_xyz(o + d z) and embedding_dir(d) (nerf.py:21-38,
+    rendering.py:186,206-207) — the X operands of xyz_encoding_1, the skip layer and dir_encoding — from the rays and the depths
+    instead of reading the six encoding slabs of every saved tile block.  Same arithmetic as the forward, so with those slabs
+    NaN-poisoned the 24 gradients are BIT-identical to the ones computed from the saved slabs (one workgroup per job at this size:
+    the same split plan, hence the same summation order)."""
+    from nerf_pl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    (m,), _ = build_models([O.make_params(5, 3.0, 0.1)], dev, "bf16")
+    rays = O.make_rays(9, B).to(dev)
+    z = (2.0 + 4.0 * torch.rand(B, S, generator=g)).sort(-1)[0].to(dev)
+    n = B * S
+    acts = ops.alloc_acts(n, "bf16", dev)
+    raw = ops.mlp_fwd_rays(rays, z, m.packed_weights("bf16"), False, "bf16", save=acts)
+    g_out = torch.randn(n, 4, generator=g).to(dev)
+    pb = m.packed_weights_bwd("bf16")
+    ((_, _, ref),) = ops.mlp_bwd_multi([(g_out, raw, pb, acts)], "bf16")
+    ref = ref.clone()
+    assert torch.isfinite(ref).all() and ref.abs().max().item() > 0
+    _poison_slots(acts, 158 * 1024 + 9 * 1024, 0, 6, 1024)               # kActEncX = 0 (4 slabs), kActEncD = 4 (2 slabs)
+    ((_, _, bad),) = ops.mlp_bwd_multi([(g_out, raw, pb, acts)], "bf16")
+    assert not torch.isfinite(bad).all()                                  # (the poison is where the launch reads without the rays)
+    ((_, _, got),) = ops.mlp_bwd_multi([(g_out, raw, pb, acts, rays, z)], "bf16")
+    assert torch.equal(got, ref)

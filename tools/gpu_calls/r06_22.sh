@@ -1,0 +1,13 @@
+# r06 call 22: regenerated encodings with the rays by SCALAR loads (call 21: a vector load in the loop made hipcc drain vmcnt = the DMA ring
+# every iteration, dW 400 -> 600 us): the new tests, the gradient / step suites, same-tree ABAB through NERFHIP_REGEN_ENC=0 | 1
+set -u
+OUT=gpurun_out/r06_22; mkdir -p $OUT
+( time timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_training.py tests/test_gpu_fused_step.py tests/test_gpu_bf16.py tests/test_gpu_render_fused.py tests/test_gpu_layered.py tests/test_gpu_inference.py tests/test_gpu_draws.py -q -m gpu -s 2>&1 | grep -E "passed|failed|FAILED|Error|assert|regenerated vs saved" | cut -c1-400 ) 2>&1 | tee $OUT/pytest_subset.txt
+for rep in 1 2 3; do
+  for R in 0 1; do
+    NERFHIP_REGEN_ENC=$R python bench.py --no-cpu-baseline --no-extras --no-pmc --steps 60 --warmup 10 2>/dev/null | R=$R python -c "
+import json,sys,os
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('regen_enc=%s' % os.environ['R'], 'sustained', d['ms_per_step'], 'literal', d['literal_contract']['ms_per_step'], [(k['kernel'][:20], k['in_step_launch_us'], k['avg_launch_us']) for k in d['roofline_kernels']], 'non-mlp', d['non_mlp_us'])"
+  done
+done | tee $OUT/regen_abab.txt
