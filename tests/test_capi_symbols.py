@@ -148,3 +148,29 @@ def test_linear_entry_points_validate_arguments_without_a_gpu(lib):
     big = ws(196608, 256, 256)        # 2 x 1 tiles of 128 x 256: 512 two-tile workgroup equivalents => 256 splits of 768 points
     assert big == 256 * (256 * 256 + 256) * 4
     assert ws(196608, 319, 256) == 128 * (256 * 512 + 256) * 4      # two 256-column tiles per row of tiles: half the splits
+
+
+def test_bwd_multi_rays_refuses_what_it_cannot_regenerate(lib):
+    """nerfhip_mlp_bwd_multi_rays validates its encoding source before anything is launched or dereferenced (host logic: runs
+    without a GPU): only the bf16 arithmetic regenerates, S must be a whole number of 32-point tiles, n a whole number of
+    256-point workgroups and of rays, the arrays 16-byte aligned."""
+    import ctypes
+    from nerf_pl_amd import _lib
+    vp = ctypes.c_void_p
+    fake = 0x10000                                                     # never dereferenced: every call below returns from the checks
+    one = (vp * 1)(fake)
+    grads = (vp * 12)(*([fake] * 12))
+    F32, BF16, BF16_F8 = 0, 1, 2
+
+    def call(n, dtype, rays=fake, z=fake, S=64):
+        enc = _lib.EncSource()
+        enc.rays[0], enc.z[0], enc.S[0] = rays, z, S
+        n_arr = (ctypes.c_int64 * 1)(n)
+        return lib.nerfhip_mlp_bwd_multi_rays(1, one, one, n_arr, one, one, one, vp(fake), grads, grads, 0, dtype, 7, None, None,
+                                              ctypes.addressof(enc), None)
+    assert call(64 * 64, F32) == -2 and call(64 * 64, BF16_F8) == -2    # NERFHIP_E_UNSUPPORTED
+    assert call(64 * 48, BF16, S=48) == -1                             # S not a multiple of 32
+    assert call(64 * 64 + 32, BF16) == -1                              # n not a multiple of 256
+    assert call(64 * 64, BF16, z=fake + 4) == -3                       # NERFHIP_E_ALIGN
+    assert call(64 * 64, BF16, z=None) == -1                           # rays without depths
+    assert call(64 * 64, 7) == -2
